@@ -1,0 +1,161 @@
+/*
+ * stark_hip.h -- C ABI of the MI355X (gfx950) implementation of the STARK
+ * prover hot path: NTT / coset low-degree extension / FRI split-and-fold /
+ * BLAKE2b Merkle commitment over p = 407 * 2^119 + 1.
+ *
+ * These are the entry points an FFI binding of the reference crate
+ * (`zk_stark`, src/modules/*.rs) binds; each one names the reference function
+ * it stands in for.  Conventions:
+ *   - a field element is 16 bytes: two little-endian uint64_t {lo, hi}, a
+ *     canonical integer in [0, p) (the packed image of FieldElement.value,
+ *     field.rs:11-14);
+ *   - every function returns 0 on success or a STARK_E* code; the message of
+ *     the last failure on the calling thread is stark_last_error().  The
+ *     reference panics instead (ntt.rs:15-16,26,32; merkle.rs:18,55-56;
+ *     fri.rs:34,116); a binding re-raises the code as the same panic text;
+ *   - functions without a suffix take HOST pointers and copy in/out;
+ *     functions ending in _dev take DEVICE pointers and enqueue on the
+ *     context's stream without a host sync (except where a result is returned
+ *     to the host, e.g. a root);
+ *   - one context per process per GPU; a context is used by one thread at a
+ *     time.
+ */
+#ifndef STARK_HIP_H
+#define STARK_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct stark_ctx stark_ctx;
+typedef struct stark_tree stark_tree;             /* retained Merkle tree (device) */
+typedef struct stark_fri_layers stark_fri_layers; /* codewords + trees of one Fri::commit */
+
+enum {
+    STARK_OK = 0,
+    STARK_ENOTPOW2 = 1,   /* "NTT size must be power of 2" / "length must be power of two" */
+    STARK_ETOOLARGE = 2,  /* "NTT size too large for practical use" (ntt.rs:16) */
+    STARK_ELENGTH = 3,    /* "Input size must match NTT size" and other length mismatches */
+    STARK_EINDEX = 4,     /* "cannot open invalid index" (merkle.rs:56) */
+    STARK_EROUNDS = 5,    /* "Cannot do FRI with less than 1 round" (fri.rs:34) */
+    STARK_EORDER = 6,     /* "error in commit: omega does not have the right order!" (fri.rs:116) */
+    STARK_EARG = 7,       /* null pointer / bad argument */
+    STARK_EHIP = 8,       /* HIP runtime error */
+    STARK_ENOMEM = 9,     /* device or host allocation failed */
+    STARK_ECALLBACK = 10  /* transcript callback returned non-zero */
+};
+
+/* ---- context ------------------------------------------------------------ */
+int32_t stark_ctx_create(int32_t device, stark_ctx** out);
+void stark_ctx_destroy(stark_ctx* ctx);
+/* Run on an existing hipStream_t (e.g. the caller's current stream); NULL = the context's own stream. */
+int32_t stark_ctx_set_stream(stark_ctx* ctx, void* hip_stream);
+int32_t stark_ctx_synchronize(stark_ctx* ctx);
+const char* stark_last_error(void);
+
+/* ---- device memory helpers (for callers that keep vectors resident) ------ */
+int32_t stark_dev_alloc(stark_ctx* ctx, size_t bytes, void** dptr);
+int32_t stark_dev_free(stark_ctx* ctx, void* dptr);
+int32_t stark_copy_h2d(stark_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+int32_t stark_copy_d2h(stark_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+
+/* ---- NTT ------------------------------------------------------------------
+ * NTT::forward / NTT::inverse (ntt.rs:25-40): in place, natural order in and
+ * out, omega = primitive_nth_root(n) (field.rs:96-107); the inverse uses
+ * omega^-1 and scales by n^-1.  n must be a power of two <= 2^30. */
+int32_t stark_ntt(stark_ctx* ctx, uint64_t* data, size_t n, int32_t inverse);
+int32_t stark_ntt_dev(stark_ctx* ctx, uint64_t* data_dev, size_t n, int32_t inverse);
+/* n_cols independent transforms; column c starts at data + 2*c*col_stride (col_stride in elements, >= n). */
+int32_t stark_ntt_batch(stark_ctx* ctx, uint64_t* data, size_t n, size_t n_cols, size_t col_stride,
+                        int32_t inverse);
+int32_t stark_ntt_batch_dev(stark_ctx* ctx, uint64_t* data_dev, size_t n, size_t n_cols, size_t col_stride,
+                            int32_t inverse);
+
+/* Coset low-degree extension, the fast path behind Polynomial::eval_domain
+ * (univariate_poly.rs:44-54) for a domain offset * omega_n^i, i < n_out:
+ *   out[c][i] = sum_j coeffs[c][j] * (offset * omega^i)^j,
+ * coefficients lowest degree first, n_coeffs <= n_out (zero padded), n_out a
+ * power of two.  With offset = 1 this is NTT::evaluate (ntt.rs:101-107).
+ * Strides are in elements. */
+int32_t stark_coset_lde_batch(stark_ctx* ctx, const uint64_t* coeffs, size_t n_coeffs, size_t coeff_stride,
+                              size_t n_cols, size_t n_out, const uint64_t offset[2], uint64_t* out,
+                              size_t out_stride);
+int32_t stark_coset_lde_batch_dev(stark_ctx* ctx, const uint64_t* coeffs_dev, size_t n_coeffs,
+                                  size_t coeff_stride, size_t n_cols, size_t n_out, const uint64_t offset[2],
+                                  uint64_t* out_dev, size_t out_stride);
+
+/* Pointwise product out[i] = a[i]*b[i] (the middle step of NTT::multiply, ntt.rs:125-127). */
+int32_t stark_vec_mul(stark_ctx* ctx, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
+int32_t stark_vec_mul_dev(stark_ctx* ctx, const uint64_t* a_dev, const uint64_t* b_dev, uint64_t* out_dev,
+                          size_t n);
+
+/* ---- Merkle ------------------------------------------------------------------
+ * Merkle::commit (merkle.rs:38-51) over the leaves
+ * bincode::serialize(&FieldElement) of n field elements (fri.rs:119,
+ * stark.rs:302): leaf = BLAKE2b-256(bytes), node = BLAKE2b-256(left||right).
+ * n must be a power of two.  If tree_out is non-NULL the whole tree stays on
+ * the device for stark_merkle_open (free with stark_tree_free). */
+int32_t stark_merkle_commit_fe(stark_ctx* ctx, const uint64_t* elems, size_t n, uint8_t root[32],
+                               stark_tree** tree_out);
+int32_t stark_merkle_commit_fe_dev(stark_ctx* ctx, const uint64_t* elems_dev, size_t n, uint8_t root[32],
+                                   stark_tree** tree_out);
+/* Merkle::commit(&Vec<Vec<u8>>) for arbitrary byte leaves: leaf i is
+ * flat[offsets[i] .. offsets[i+1]) (host pointers). */
+int32_t stark_merkle_commit_bytes(stark_ctx* ctx, const uint8_t* flat, const uint64_t* offsets, size_t n,
+                                  uint8_t root[32], stark_tree** tree_out);
+/* Merkle::open (merkle.rs:54-93): path[0] = sibling leaf digest ... last =
+ * sibling of the root's child; writes log2(n) digests of 32 bytes. */
+int32_t stark_merkle_open(stark_tree* tree, size_t index, uint8_t* path_out, size_t* depth_out);
+size_t stark_tree_num_leaves(const stark_tree* tree);
+/* All 2n-1 digests, leaf level first, each level followed by its parent level. */
+int32_t stark_tree_download(stark_tree* tree, uint8_t* out);
+void stark_tree_free(stark_tree* tree);
+
+/* ---- FRI ---------------------------------------------------------------------
+ * One split-and-fold step (fri.rs:133-138), N even:
+ *   out[i] = 2^-1((1 + alpha/(offset*omega^i)) cw[i] + (1 - alpha/(offset*omega^i)) cw[N/2+i]). */
+int32_t stark_fri_fold(stark_ctx* ctx, const uint64_t* codeword, size_t N, const uint64_t alpha[2],
+                       const uint64_t offset[2], const uint64_t omega[2], uint64_t* out);
+int32_t stark_fri_fold_dev(stark_ctx* ctx, const uint64_t* codeword_dev, size_t N, const uint64_t alpha[2],
+                           const uint64_t offset[2], const uint64_t omega[2], uint64_t* out_dev);
+
+/* Fri::num_rounds (fri.rs:39-51). */
+size_t stark_fri_num_rounds(size_t domain_length, size_t expansion_factor, size_t num_colinearity_tests);
+
+/* The host owns the Fiat-Shamir transcript (ProofStream, proof_stream.rs).
+ * Called once per round r < num_rounds with that layer's Merkle root (the
+ * binding pushes hex::encode(root), fri.rs:120); for every round but the last
+ * it must return alpha = FieldElement::sample(prover_fiat_shamir(32))
+ * (fri.rs:126-127) in alpha_out.  `last` is 1 on the final round (alpha_out is
+ * ignored).  Return non-zero to abort. */
+typedef int32_t (*stark_transcript_cb)(void* user, uint32_t round, int32_t last, const uint8_t root[32],
+                                       uint64_t alpha_out[2]);
+
+/* Fri::commit (fri.rs:100-152) with the fold loop, per-layer leaf hashing and
+ * trees on the device.  The codewords (all num_rounds of them, as the
+ * reference returns) and their trees stay resident in *layers_out. */
+int32_t stark_fri_commit(stark_ctx* ctx, const uint64_t* codeword, size_t N, const uint64_t offset[2],
+                         const uint64_t omega[2], size_t expansion_factor, size_t num_colinearity_tests,
+                         stark_transcript_cb cb, void* user, stark_fri_layers** layers_out);
+int32_t stark_fri_commit_dev(stark_ctx* ctx, const uint64_t* codeword_dev, size_t N, const uint64_t offset[2],
+                             const uint64_t omega[2], size_t expansion_factor, size_t num_colinearity_tests,
+                             stark_transcript_cb cb, void* user, stark_fri_layers** layers_out);
+size_t stark_fri_layers_count(const stark_fri_layers* l);
+size_t stark_fri_layer_len(const stark_fri_layers* l, size_t layer);
+int32_t stark_fri_layer_root(const stark_fri_layers* l, size_t layer, uint8_t root[32]);
+int32_t stark_fri_layer_download(stark_fri_layers* l, size_t layer, uint64_t* out);
+/* Gather `count` elements of a layer (the reads of Fri::query, fri.rs:166-179). */
+int32_t stark_fri_layer_read(stark_fri_layers* l, size_t layer, const uint64_t* indices, size_t count,
+                             uint64_t* out);
+/* Merkle::open on a layer's retained tree (fri.rs:187,194,201). */
+int32_t stark_fri_layer_open(stark_fri_layers* l, size_t layer, size_t index, uint8_t* path_out,
+                             size_t* depth_out);
+void stark_fri_layers_free(stark_fri_layers* l);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STARK_HIP_H */

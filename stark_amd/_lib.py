@@ -1,0 +1,79 @@
+"""Loads libstark_hip.so (the HIP kernels + C ABI of include/stark_hip.h) with
+ctypes.  There is no fallback: if the library is missing or has no GPU to run
+on, calls fail loudly."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libstark_hip.so")
+
+u64p = C.POINTER(C.c_uint64)
+u8p = C.POINTER(C.c_uint8)
+voidpp = C.POINTER(C.c_void_p)
+szp = C.POINTER(C.c_size_t)
+sz = C.c_size_t
+i32 = C.c_int32
+
+TRANSCRIPT_CB = C.CFUNCTYPE(i32, C.c_void_p, C.c_uint32, i32, u8p, u64p)
+
+# name -> (restype, argtypes); mirrors include/stark_hip.h one to one
+SIGNATURES = {
+    "stark_last_error": (C.c_char_p, []),
+    "stark_ctx_create": (i32, [i32, voidpp]),
+    "stark_ctx_destroy": (None, [C.c_void_p]),
+    "stark_ctx_set_stream": (i32, [C.c_void_p, C.c_void_p]),
+    "stark_ctx_synchronize": (i32, [C.c_void_p]),
+    "stark_dev_alloc": (i32, [C.c_void_p, sz, voidpp]),
+    "stark_dev_free": (i32, [C.c_void_p, C.c_void_p]),
+    "stark_copy_h2d": (i32, [C.c_void_p, C.c_void_p, C.c_void_p, sz]),
+    "stark_copy_d2h": (i32, [C.c_void_p, C.c_void_p, C.c_void_p, sz]),
+    "stark_ntt": (i32, [C.c_void_p, C.c_void_p, sz, i32]),
+    "stark_ntt_dev": (i32, [C.c_void_p, C.c_void_p, sz, i32]),
+    "stark_ntt_batch": (i32, [C.c_void_p, C.c_void_p, sz, sz, sz, i32]),
+    "stark_ntt_batch_dev": (i32, [C.c_void_p, C.c_void_p, sz, sz, sz, i32]),
+    "stark_coset_lde_batch": (i32, [C.c_void_p, C.c_void_p, sz, sz, sz, sz, u64p, C.c_void_p, sz]),
+    "stark_coset_lde_batch_dev": (i32, [C.c_void_p, C.c_void_p, sz, sz, sz, sz, u64p, C.c_void_p, sz]),
+    "stark_vec_mul": (i32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, sz]),
+    "stark_vec_mul_dev": (i32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, sz]),
+    "stark_merkle_commit_fe": (i32, [C.c_void_p, C.c_void_p, sz, u8p, voidpp]),
+    "stark_merkle_commit_fe_dev": (i32, [C.c_void_p, C.c_void_p, sz, u8p, voidpp]),
+    "stark_merkle_commit_bytes": (i32, [C.c_void_p, C.c_void_p, C.c_void_p, sz, u8p, voidpp]),
+    "stark_merkle_open": (i32, [C.c_void_p, sz, u8p, szp]),
+    "stark_tree_num_leaves": (sz, [C.c_void_p]),
+    "stark_tree_download": (i32, [C.c_void_p, C.c_void_p]),
+    "stark_tree_free": (None, [C.c_void_p]),
+    "stark_fri_fold": (i32, [C.c_void_p, C.c_void_p, sz, u64p, u64p, u64p, C.c_void_p]),
+    "stark_fri_fold_dev": (i32, [C.c_void_p, C.c_void_p, sz, u64p, u64p, u64p, C.c_void_p]),
+    "stark_fri_num_rounds": (sz, [sz, sz, sz]),
+    "stark_fri_commit": (i32, [C.c_void_p, C.c_void_p, sz, u64p, u64p, sz, sz, TRANSCRIPT_CB, C.c_void_p, voidpp]),
+    "stark_fri_commit_dev": (i32, [C.c_void_p, C.c_void_p, sz, u64p, u64p, sz, sz, TRANSCRIPT_CB, C.c_void_p, voidpp]),
+    "stark_fri_layers_count": (sz, [C.c_void_p]),
+    "stark_fri_layer_len": (sz, [C.c_void_p, sz]),
+    "stark_fri_layer_root": (i32, [C.c_void_p, sz, u8p]),
+    "stark_fri_layer_download": (i32, [C.c_void_p, sz, C.c_void_p]),
+    "stark_fri_layer_read": (i32, [C.c_void_p, sz, u64p, sz, C.c_void_p]),
+    "stark_fri_layer_open": (i32, [C.c_void_p, sz, sz, u8p, szp]),
+    "stark_fri_layers_free": (None, [C.c_void_p]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Returns the loaded library; raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build it with `make -C stark_amd/csrc` "
+            "(or python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if a declared symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib

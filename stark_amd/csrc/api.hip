@@ -1,0 +1,911 @@
+// C-ABI layer: contexts, twiddle/power tables, scratch, and the entry points
+// declared in include/stark_hip.h.
+#include <hip/hip_runtime.h>
+
+#include <array>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <tuple>
+#include <utility>
+#include <vector>
+
+#include "../../include/stark_hip.h"
+#include "field_host.hpp"
+#include "internal.hpp"
+
+using namespace starkf;
+using starkh::digest;
+using namespace starkk;
+
+static thread_local std::string g_last_error;
+
+static int32_t fail(int32_t code, const std::string& msg)
+{
+    g_last_error = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(e_ == hipErrorOutOfMemory ? STARK_ENOMEM : STARK_EHIP,                     \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                        \
+    } while (0)
+
+#define ST_TRY(expr)                  \
+    do {                              \
+        int32_t rc_ = (expr);         \
+        if (rc_ != STARK_OK) return rc_; \
+    } while (0)
+
+namespace {
+
+struct NttTables {
+    uint32_t log_n = 0, h = 0;
+    std::vector<uint32_t> radices;   // empty for the single-workgroup path
+    fe* tw16 = nullptr;
+    fe* tw256 = nullptr;
+    fe* hi = nullptr;
+    fe* lo = nullptr;
+    fe* small = nullptr;             // omega_n^i, i < n/2 (n <= 4096)
+    fe scale_m{0, 0};                // n^-1, Montgomery form
+};
+
+struct PowTables {                   // powers of one element x: lo[i] = x^i (i<256), hi[i] = x^(256 i)
+    fe* hi = nullptr;
+    fe* lo = nullptr;
+    size_t hi_len = 0;
+};
+
+typedef std::tuple<uint64_t, uint64_t, uint64_t> PowKey;   // (x.lo, x.hi, hi_len)
+
+}  // namespace
+
+struct stark_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    HostField F;
+    std::map<uint32_t, NttTables> ntt_tables;          // key = log_n*2 + inverse
+    std::map<PowKey, PowTables> pow_tables;
+    fe* scratch = nullptr;
+    size_t scratch_elems = 0;
+    std::multimap<size_t, void*> pool;                 // cached device blocks by size
+    void* pinned = nullptr;                            // small pinned staging buffer (4 KiB)
+};
+
+struct stark_tree {
+    stark_ctx* ctx;
+    digest* d;        // 2n-1 digests
+    size_t n;
+    bool owns;
+};
+
+struct stark_fri_layers {
+    stark_ctx* ctx;
+    fe* cw_arena = nullptr;
+    digest* tree_arena = nullptr;
+    size_t cw_bytes = 0, tree_bytes = 0;
+    std::vector<size_t> len;
+    std::vector<fe*> cw;
+    std::vector<digest*> tree;
+    std::vector<std::array<uint8_t, 32>> roots;
+};
+
+namespace {
+
+static int log2_exact(size_t n)
+{
+    if (n == 0 || (n & (n - 1))) return -1;
+    int l = 0;
+    while (((size_t)1 << l) < n) l++;
+    return l;
+}
+
+static int32_t pool_alloc(stark_ctx* ctx, size_t bytes, void** out)
+{
+    if (bytes == 0) bytes = 16;
+    auto it = ctx->pool.find(bytes);
+    if (it != ctx->pool.end()) {
+        *out = it->second;
+        ctx->pool.erase(it);
+        return STARK_OK;
+    }
+    hipError_t e = hipMalloc(out, bytes);
+    if (e != hipSuccess) {
+        // drop the cache and retry once
+        for (auto& kv : ctx->pool) (void)hipFree(kv.second);
+        ctx->pool.clear();
+        e = hipMalloc(out, bytes);
+    }
+    if (e != hipSuccess) return fail(STARK_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+    return STARK_OK;
+}
+
+static void pool_free(stark_ctx* ctx, void* p, size_t bytes)
+{
+    if (!p) return;
+    if (bytes == 0) bytes = 16;
+    // keep at most a handful of cached blocks
+    if (ctx->pool.size() >= 16) {
+        (void)hipFree(p);
+        return;
+    }
+    ctx->pool.emplace(bytes, p);
+}
+
+static int32_t upload(stark_ctx* ctx, const std::vector<fe>& v, fe** out)
+{
+    HIP_TRY(hipMalloc((void**)out, v.size() * sizeof(fe)));
+    HIP_TRY(hipMemcpy(*out, v.data(), v.size() * sizeof(fe), hipMemcpyHostToDevice));
+    (void)ctx;
+    return STARK_OK;
+}
+
+// powers x^0, x^1, ... (canonical x) in Montgomery form
+static std::vector<fe> powers_m(const HostField& F, fe x, size_t count)
+{
+    std::vector<fe> v(count);
+    fe xm = F.to_mont(x);
+    fe cur = F.one_m;
+    for (size_t i = 0; i < count; i++) {
+        v[i] = cur;
+        cur = mont_mul(cur, xm);
+    }
+    return v;
+}
+
+static std::vector<uint32_t> plan_radices(uint32_t log_n)
+{
+    std::vector<uint32_t> r;
+    if (log_n <= (uint32_t)SMALL_MAX_LOG) return r;
+    uint32_t P = (log_n + 7) / 8;
+    uint32_t base = log_n / P, rem = log_n % P;
+    for (uint32_t q = 0; q < P; q++) r.push_back(base + (q < rem ? 1 : 0));
+    return r;
+}
+
+static int32_t get_ntt_tables(stark_ctx* ctx, uint32_t log_n, bool inverse, const NttTables** out)
+{
+    uint32_t key = log_n * 2 + (inverse ? 1 : 0);
+    auto it = ctx->ntt_tables.find(key);
+    if (it != ctx->ntt_tables.end()) {
+        *out = &it->second;
+        return STARK_OK;
+    }
+    const HostField& F = ctx->F;
+    NttTables t;
+    t.log_n = log_n;
+    fe omega = F.primitive_nth_root(log_n);                   // ntt.rs:18
+    if (inverse) omega = F.inverse(omega);                    // ntt.rs:19
+    fe n_inv = F.inverse(fe{(u64)1 << log_n, 0});             // ntt.rs:36
+    t.scale_m = F.to_mont(n_inv);
+    if (log_n <= (uint32_t)SMALL_MAX_LOG) {
+        size_t half = log_n ? ((size_t)1 << (log_n - 1)) : 1;
+        ST_TRY(upload(ctx, powers_m(F, omega, half), &t.small));
+    } else {
+        t.radices = plan_radices(log_n);
+        t.h = t.radices.back();
+        fe w16 = F.pow(omega, (u128)1 << (log_n - 4));
+        fe w256 = F.pow(omega, (u128)1 << (log_n - 8));
+        ST_TRY(upload(ctx, powers_m(F, w16, 8), &t.tw16));
+        ST_TRY(upload(ctx, powers_m(F, w256, 256), &t.tw256));
+        fe w_hi = F.pow(omega, (u128)1 << t.h);
+        ST_TRY(upload(ctx, powers_m(F, w_hi, (size_t)1 << (log_n - t.h)), &t.hi));
+        std::vector<fe> lo = powers_m(F, omega, (size_t)1 << t.h);
+        if (inverse)
+            for (auto& x : lo) x = mont_mul(x, t.scale_m);    // fold n^-1 into the last-pass twiddle
+        ST_TRY(upload(ctx, lo, &t.lo));
+    }
+    auto ins = ctx->ntt_tables.emplace(key, t);
+    *out = &ins.first->second;
+    return STARK_OK;
+}
+
+static int32_t get_pow_tables(stark_ctx* ctx, fe x, size_t count, const PowTables** out)
+{
+    size_t hi_len = (count + 255) / 256;
+    if (hi_len == 0) hi_len = 1;
+    PowKey key(x.lo, x.hi, hi_len);
+    auto it = ctx->pow_tables.find(key);
+    if (it != ctx->pow_tables.end()) {
+        *out = &it->second;
+        return STARK_OK;
+    }
+    if (ctx->pow_tables.size() >= 32) {                       // bounded cache
+        for (auto& kv : ctx->pow_tables) {
+            (void)hipFree(kv.second.hi);
+            (void)hipFree(kv.second.lo);
+        }
+        ctx->pow_tables.clear();
+    }
+    const HostField& F = ctx->F;
+    PowTables t;
+    t.hi_len = hi_len;
+    ST_TRY(upload(ctx, powers_m(F, x, 256), &t.lo));
+    ST_TRY(upload(ctx, powers_m(F, F.pow(x, 256), hi_len), &t.hi));
+    auto ins = ctx->pow_tables.emplace(key, t);
+    *out = &ins.first->second;
+    return STARK_OK;
+}
+
+static int32_t ensure_scratch(stark_ctx* ctx, size_t elems)
+{
+    if (ctx->scratch_elems >= elems) return STARK_OK;
+    if (ctx->scratch) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        HIP_TRY(hipFree(ctx->scratch));
+        ctx->scratch = nullptr;
+        ctx->scratch_elems = 0;
+    }
+    HIP_TRY(hipMalloc((void**)&ctx->scratch, elems * sizeof(fe)));
+    ctx->scratch_elems = elems;
+    return STARK_OK;
+}
+
+// Transform n_cols columns: column c reads n_src elements at src + c*src_stride
+// (zero padded to n), writes n elements at dst + c*dst_stride.  All device
+// pointers.  twist == nullptr means offset 1.
+static int32_t run_ntt(stark_ctx* ctx, const fe* src, size_t src_stride, size_t n_src, fe* dst,
+                       size_t dst_stride, uint32_t log_n, bool inverse, const PowTables* twist, size_t n_cols)
+{
+    if (n_cols == 0) return STARK_OK;
+    const NttTables* t;
+    ST_TRY(get_ntt_tables(ctx, log_n, inverse, &t));
+    const size_t n = (size_t)1 << log_n;
+    if (log_n <= (uint32_t)SMALL_MAX_LOG) {
+        SmallArgs a{};
+        a.tw = t->small;
+        a.twist_hi = twist ? twist->hi : nullptr;
+        a.twist_lo = twist ? twist->lo : nullptr;
+        a.scale_m = t->scale_m;
+        a.src_batch_stride = src_stride;
+        a.dst_batch_stride = dst_stride;
+        a.n_src = n_src;
+        a.log_n = log_n;
+        a.has_scale = inverse ? 1 : 0;
+        a.has_twist = twist ? 1 : 0;
+        for (size_t c0 = 0; c0 < n_cols; c0 += 65535) {
+            size_t nb = n_cols - c0 < 65535 ? n_cols - c0 : 65535;
+            a.src = src + c0 * src_stride;
+            a.dst = dst + c0 * dst_stride;
+            HIP_TRY(launch_ntt_small(a, (uint32_t)nb, ctx->stream));
+        }
+        return STARK_OK;
+    }
+    // scratch-bounded chunks of columns
+    size_t chunk = ((size_t)1 << 26) / n;
+    if (chunk == 0) chunk = 1;
+    if (chunk > n_cols) chunk = n_cols;
+    if (chunk > 65535) chunk = 65535;
+    ST_TRY(ensure_scratch(ctx, chunk * n));
+    const size_t P = t->radices.size();
+    for (size_t c0 = 0; c0 < n_cols; c0 += chunk) {
+        const size_t nb = n_cols - c0 < chunk ? n_cols - c0 : chunk;
+        uint32_t log_s = log_n;
+        for (size_t q = 0; q < P; q++) {
+            log_s -= t->radices[q];
+            PassArgs a{};
+            a.tw16 = t->tw16;
+            a.tw256 = t->tw256;
+            a.hi = t->hi;
+            a.lo = t->lo;
+            a.log_n = log_n;
+            a.log_s = log_s;
+            a.r = t->radices[q];
+            a.h = t->h;
+            a.nprev = (uint32_t)q;
+            for (size_t u = 0; u < q; u++) a.rprev[u] = t->radices[u];
+            a.n_src = n;
+            PassMode mode;
+            if (q == 0) {
+                mode = PASS_FIRST;
+                a.src = src + c0 * src_stride;
+                a.src_batch_stride = src_stride;
+                a.n_src = n_src;
+                a.twist_hi = twist ? twist->hi : nullptr;
+                a.twist_lo = twist ? twist->lo : nullptr;
+            } else {
+                mode = (q == P - 1) ? PASS_LAST : PASS_MIDDLE;
+                a.src = ctx->scratch;
+                a.src_batch_stride = n;
+            }
+            if (q == P - 1) {
+                a.dst = dst + c0 * dst_stride;
+                a.dst_batch_stride = dst_stride;
+            } else {
+                a.dst = ctx->scratch;
+                a.dst_batch_stride = n;
+            }
+            HIP_TRY(launch_ntt_pass(a, mode, q == 0 && twist != nullptr, (uint32_t)nb, ctx->stream));
+        }
+    }
+    return STARK_OK;
+}
+
+static bool is_one(fe x) { return x.lo == 1 && x.hi == 0; }
+static bool is_canonical(fe x) { return !ge_p(x.lo, x.hi); }
+
+// RAII staging buffer for the host-pointer entry points
+struct DevBuf {
+    stark_ctx* ctx;
+    void* p = nullptr;
+    size_t bytes = 0;
+    explicit DevBuf(stark_ctx* c) : ctx(c) {}
+    int32_t alloc(size_t b)
+    {
+        bytes = b;
+        return pool_alloc(ctx, b, &p);
+    }
+    ~DevBuf() { pool_free(ctx, p, bytes); }
+};
+
+static int32_t tree_build(stark_ctx* ctx, const fe* elems_dev, size_t n, uint8_t root[32], stark_tree** tree_out)
+{
+    if (log2_exact(n) < 0) return fail(STARK_ENOTPOW2, "length must be power of two");
+    const size_t bytes = (2 * n - 1) * sizeof(digest);
+    void* d = nullptr;
+    ST_TRY(pool_alloc(ctx, bytes, &d));
+    digest* tree = (digest*)d;
+    hipError_t e = launch_leaf_hash(elems_dev, tree, n, ctx->stream);
+    if (e == hipSuccess) e = launch_merkle_reduce(tree, n, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(ctx->pinned, tree + (2 * n - 2), 32, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        pool_free(ctx, d, bytes);
+        return fail(STARK_EHIP, std::string("merkle commit: ") + hipGetErrorString(e));
+    }
+    memcpy(root, ctx->pinned, 32);
+    if (tree_out) {
+        *tree_out = new stark_tree{ctx, tree, n, true};
+    } else {
+        pool_free(ctx, d, bytes);
+    }
+    return STARK_OK;
+}
+
+static int32_t tree_open(stark_ctx* ctx, const digest* tree, size_t n, size_t index, uint8_t* path_out,
+                         size_t* depth_out)
+{
+    int depth = log2_exact(n);
+    if (depth < 0) return fail(STARK_ENOTPOW2, "length must be power of two");
+    if (index >= n) return fail(STARK_EINDEX, "cannot open invalid index");
+    if (depth_out) *depth_out = (size_t)depth;
+    if (depth == 0) return STARK_OK;
+    digest* stage = (digest*)((uint8_t*)ctx->pinned + 64);     // 4 KiB pinned buffer: depth <= 30 digests fit
+    DevBuf tmp(ctx);
+    ST_TRY(tmp.alloc((size_t)depth * sizeof(digest)));
+    HIP_TRY(launch_merkle_open(tree, n, index, (digest*)tmp.p, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(stage, tmp.p, (size_t)depth * sizeof(digest), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    memcpy(path_out, stage, (size_t)depth * sizeof(digest));
+    return STARK_OK;
+}
+
+}  // namespace
+
+// ===========================================================================
+// context
+// ===========================================================================
+extern "C" const char* stark_last_error(void) { return g_last_error.c_str(); }
+
+extern "C" int32_t stark_ctx_create(int32_t device, stark_ctx** out)
+{
+    if (!out) return fail(STARK_EARG, "stark_ctx_create: null out");
+    int count = 0;
+    HIP_TRY(hipGetDeviceCount(&count));
+    if (device < 0 || device >= count) return fail(STARK_EARG, "stark_ctx_create: no such device");
+    HIP_TRY(hipSetDevice(device));
+    stark_ctx* ctx = new stark_ctx();
+    ctx->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipHostMalloc(&ctx->pinned, 4096, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        delete ctx;
+        return fail(STARK_EHIP, std::string("stark_ctx_create: ") + hipGetErrorString(e));
+    }
+    ctx->stream = ctx->own_stream;
+    *out = ctx;
+    return STARK_OK;
+}
+
+extern "C" void stark_ctx_destroy(stark_ctx* ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& kv : ctx->ntt_tables) {
+        NttTables& t = kv.second;
+        (void)hipFree(t.tw16); (void)hipFree(t.tw256); (void)hipFree(t.hi); (void)hipFree(t.lo); (void)hipFree(t.small);
+    }
+    for (auto& kv : ctx->pow_tables) { (void)hipFree(kv.second.hi); (void)hipFree(kv.second.lo); }
+    for (auto& kv : ctx->pool) (void)hipFree(kv.second);
+    if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+extern "C" int32_t stark_ctx_set_stream(stark_ctx* ctx, void* hip_stream)
+{
+    if (!ctx) return fail(STARK_EARG, "null context");
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return STARK_OK;
+}
+
+extern "C" int32_t stark_ctx_synchronize(stark_ctx* ctx)
+{
+    if (!ctx) return fail(STARK_EARG, "null context");
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return STARK_OK;
+}
+
+extern "C" int32_t stark_dev_alloc(stark_ctx* ctx, size_t bytes, void** dptr)
+{
+    if (!ctx || !dptr) return fail(STARK_EARG, "null argument");
+    HIP_TRY(hipMalloc(dptr, bytes ? bytes : 16));
+    return STARK_OK;
+}
+
+extern "C" int32_t stark_dev_free(stark_ctx* ctx, void* dptr)
+{
+    if (!ctx) return fail(STARK_EARG, "null context");
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipFree(dptr));
+    return STARK_OK;
+}
+
+extern "C" int32_t stark_copy_h2d(stark_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes)
+{
+    if (!ctx) return fail(STARK_EARG, "null context");
+    HIP_TRY(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return STARK_OK;
+}
+
+extern "C" int32_t stark_copy_d2h(stark_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes)
+{
+    if (!ctx) return fail(STARK_EARG, "null context");
+    HIP_TRY(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return STARK_OK;
+}
+
+// ===========================================================================
+// NTT
+// ===========================================================================
+static int32_t check_ntt_size(size_t n, int* log_n)
+{
+    int l = log2_exact(n);
+    if (l < 0) return fail(STARK_ENOTPOW2, "NTT size must be power of 2");
+    if (l > 30) return fail(STARK_ETOOLARGE, "NTT size too large for practical use");
+    *log_n = l;
+    return STARK_OK;
+}
+
+extern "C" int32_t stark_ntt_batch_dev(stark_ctx* ctx, uint64_t* data_dev, size_t n, size_t n_cols,
+                                       size_t col_stride, int32_t inverse)
+{
+    if (!ctx || (!data_dev && n_cols)) return fail(STARK_EARG, "null argument");
+    int log_n;
+    ST_TRY(check_ntt_size(n, &log_n));
+    if (n_cols > 1 && col_stride < n) return fail(STARK_ELENGTH, "column stride smaller than NTT size");
+    fe* d = (fe*)data_dev;
+    return run_ntt(ctx, d, col_stride, n, d, col_stride, (uint32_t)log_n, inverse != 0, nullptr, n_cols);
+}
+
+extern "C" int32_t stark_ntt_dev(stark_ctx* ctx, uint64_t* data_dev, size_t n, int32_t inverse)
+{
+    return stark_ntt_batch_dev(ctx, data_dev, n, 1, n, inverse);
+}
+
+extern "C" int32_t stark_ntt_batch(stark_ctx* ctx, uint64_t* data, size_t n, size_t n_cols, size_t col_stride,
+                                   int32_t inverse)
+{
+    if (!ctx || (!data && n_cols)) return fail(STARK_EARG, "null argument");
+    int log_n;
+    ST_TRY(check_ntt_size(n, &log_n));
+    if (n_cols == 0) return STARK_OK;
+    if (n_cols > 1 && col_stride < n) return fail(STARK_ELENGTH, "column stride smaller than NTT size");
+    const size_t span = (n_cols - 1) * col_stride + n;
+    DevBuf buf(ctx);
+    ST_TRY(buf.alloc(span * sizeof(fe)));
+    HIP_TRY(hipMemcpyAsync(buf.p, data, span * sizeof(fe), hipMemcpyHostToDevice, ctx->stream));
+    ST_TRY(stark_ntt_batch_dev(ctx, (uint64_t*)buf.p, n, n_cols, col_stride, inverse));
+    HIP_TRY(hipMemcpyAsync(data, buf.p, span * sizeof(fe), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return STARK_OK;
+}
+
+extern "C" int32_t stark_ntt(stark_ctx* ctx, uint64_t* data, size_t n, int32_t inverse)
+{
+    return stark_ntt_batch(ctx, data, n, 1, n, inverse);
+}
+
+extern "C" int32_t stark_coset_lde_batch_dev(stark_ctx* ctx, const uint64_t* coeffs_dev, size_t n_coeffs,
+                                             size_t coeff_stride, size_t n_cols, size_t n_out,
+                                             const uint64_t offset[2], uint64_t* out_dev, size_t out_stride)
+{
+    if (!ctx || !offset || (n_cols && (!coeffs_dev || !out_dev))) return fail(STARK_EARG, "null argument");
+    int log_n;
+    ST_TRY(check_ntt_size(n_out, &log_n));
+    if (n_coeffs > n_out) return fail(STARK_ELENGTH, "more coefficients than evaluation points");
+    if (n_cols > 1 && (coeff_stride < n_coeffs || out_stride < n_out))
+        return fail(STARK_ELENGTH, "stride smaller than column length");
+    fe off{offset[0], offset[1]};
+    if (!is_canonical(off)) return fail(STARK_EARG, "offset not reduced modulo p");
+    const PowTables* twist = nullptr;
+    if (!is_one(off) && n_coeffs > 0) ST_TRY(get_pow_tables(ctx, off, n_coeffs, &twist));
+    return run_ntt(ctx, (const fe*)coeffs_dev, coeff_stride, n_coeffs, (fe*)out_dev, out_stride, (uint32_t)log_n,
+                   false, twist, n_cols);
+}
+
+extern "C" int32_t stark_coset_lde_batch(stark_ctx* ctx, const uint64_t* coeffs, size_t n_coeffs,
+                                         size_t coeff_stride, size_t n_cols, size_t n_out,
+                                         const uint64_t offset[2], uint64_t* out, size_t out_stride)
+{
+    if (!ctx || !offset || (n_cols && (!coeffs || !out))) return fail(STARK_EARG, "null argument");
+    int log_n;
+    ST_TRY(check_ntt_size(n_out, &log_n));
+    if (n_coeffs > n_out) return fail(STARK_ELENGTH, "more coefficients than evaluation points");
+    if (n_cols == 0) return STARK_OK;
+    if (n_cols > 1 && (coeff_stride < n_coeffs || out_stride < n_out))
+        return fail(STARK_ELENGTH, "stride smaller than column length");
+    const size_t in_span = (n_cols - 1) * coeff_stride + n_coeffs;
+    const size_t out_span = (n_cols - 1) * out_stride + n_out;
+    DevBuf in(ctx), ob(ctx);
+    ST_TRY(in.alloc(in_span * sizeof(fe)));
+    ST_TRY(ob.alloc(out_span * sizeof(fe)));
+    if (in_span) HIP_TRY(hipMemcpyAsync(in.p, coeffs, in_span * sizeof(fe), hipMemcpyHostToDevice, ctx->stream));
+    ST_TRY(stark_coset_lde_batch_dev(ctx, (const uint64_t*)in.p, n_coeffs, coeff_stride, n_cols, n_out, offset,
+                                     (uint64_t*)ob.p, out_stride));
+    // only the columns are defined; copy them one by one when padded
+    if (out_stride == n_out || n_cols == 1) {
+        HIP_TRY(hipMemcpyAsync(out, ob.p, out_span * sizeof(fe), hipMemcpyDeviceToHost, ctx->stream));
+    } else {
+        for (size_t c = 0; c < n_cols; c++)
+            HIP_TRY(hipMemcpyAsync(out + 2 * c * out_stride, (fe*)ob.p + c * out_stride, n_out * sizeof(fe),
+                                   hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return STARK_OK;
+}
+
+extern "C" int32_t stark_vec_mul_dev(stark_ctx* ctx, const uint64_t* a_dev, const uint64_t* b_dev,
+                                     uint64_t* out_dev, size_t n)
+{
+    if (!ctx || (n && (!a_dev || !b_dev || !out_dev))) return fail(STARK_EARG, "null argument");
+    HIP_TRY(launch_vec_mul((const fe*)a_dev, (const fe*)b_dev, (fe*)out_dev, n, ctx->F.r2, ctx->stream));
+    return STARK_OK;
+}
+
+extern "C" int32_t stark_vec_mul(stark_ctx* ctx, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n)
+{
+    if (!ctx || (n && (!a || !b || !out))) return fail(STARK_EARG, "null argument");
+    if (n == 0) return STARK_OK;
+    DevBuf da(ctx), db(ctx);
+    ST_TRY(da.alloc(n * sizeof(fe)));
+    ST_TRY(db.alloc(n * sizeof(fe)));
+    HIP_TRY(hipMemcpyAsync(da.p, a, n * sizeof(fe), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(db.p, b, n * sizeof(fe), hipMemcpyHostToDevice, ctx->stream));
+    ST_TRY(stark_vec_mul_dev(ctx, (uint64_t*)da.p, (uint64_t*)db.p, (uint64_t*)da.p, n));
+    HIP_TRY(hipMemcpyAsync(out, da.p, n * sizeof(fe), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return STARK_OK;
+}
+
+// ===========================================================================
+// Merkle
+// ===========================================================================
+extern "C" int32_t stark_merkle_commit_fe_dev(stark_ctx* ctx, const uint64_t* elems_dev, size_t n,
+                                              uint8_t root[32], stark_tree** tree_out)
+{
+    if (!ctx || !elems_dev || !root) return fail(STARK_EARG, "null argument");
+    return tree_build(ctx, (const fe*)elems_dev, n, root, tree_out);
+}
+
+extern "C" int32_t stark_merkle_commit_fe(stark_ctx* ctx, const uint64_t* elems, size_t n, uint8_t root[32],
+                                          stark_tree** tree_out)
+{
+    if (!ctx || !elems || !root) return fail(STARK_EARG, "null argument");
+    if (log2_exact(n) < 0) return fail(STARK_ENOTPOW2, "length must be power of two");
+    DevBuf buf(ctx);
+    ST_TRY(buf.alloc(n * sizeof(fe)));
+    HIP_TRY(hipMemcpyAsync(buf.p, elems, n * sizeof(fe), hipMemcpyHostToDevice, ctx->stream));
+    return tree_build(ctx, (const fe*)buf.p, n, root, tree_out);
+}
+
+extern "C" int32_t stark_merkle_commit_bytes(stark_ctx* ctx, const uint8_t* flat, const uint64_t* offsets,
+                                             size_t n, uint8_t root[32], stark_tree** tree_out)
+{
+    if (!ctx || !offsets || !root) return fail(STARK_EARG, "null argument");
+    if (log2_exact(n) < 0) return fail(STARK_ENOTPOW2, "length must be power of two");
+    const size_t total = (size_t)offsets[n];
+    if (total && !flat) return fail(STARK_EARG, "null leaf data");
+    DevBuf dflat(ctx), doff(ctx);
+    ST_TRY(dflat.alloc(total ? total : 16));
+    ST_TRY(doff.alloc((n + 1) * sizeof(uint64_t)));
+    if (total) HIP_TRY(hipMemcpyAsync(dflat.p, flat, total, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(doff.p, offsets, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+    const size_t bytes = (2 * n - 1) * sizeof(digest);
+    void* d = nullptr;
+    ST_TRY(pool_alloc(ctx, bytes, &d));
+    digest* tree = (digest*)d;
+    hipError_t e = launch_leaf_hash_bytes((const uint8_t*)dflat.p, (const uint64_t*)doff.p, tree, n, ctx->stream);
+    if (e == hipSuccess) e = launch_merkle_reduce(tree, n, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(ctx->pinned, tree + (2 * n - 2), 32, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        pool_free(ctx, d, bytes);
+        return fail(STARK_EHIP, std::string("merkle commit: ") + hipGetErrorString(e));
+    }
+    memcpy(root, ctx->pinned, 32);
+    if (tree_out) *tree_out = new stark_tree{ctx, tree, n, true};
+    else pool_free(ctx, d, bytes);
+    return STARK_OK;
+}
+
+extern "C" int32_t stark_merkle_open(stark_tree* tree, size_t index, uint8_t* path_out, size_t* depth_out)
+{
+    if (!tree || !path_out) return fail(STARK_EARG, "null argument");
+    return tree_open(tree->ctx, tree->d, tree->n, index, path_out, depth_out);
+}
+
+extern "C" size_t stark_tree_num_leaves(const stark_tree* tree) { return tree ? tree->n : 0; }
+
+extern "C" int32_t stark_tree_download(stark_tree* tree, uint8_t* out)
+{
+    if (!tree || !out) return fail(STARK_EARG, "null argument");
+    HIP_TRY(hipMemcpyAsync(out, tree->d, (2 * tree->n - 1) * sizeof(digest), hipMemcpyDeviceToHost,
+                           tree->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(tree->ctx->stream));
+    return STARK_OK;
+}
+
+extern "C" void stark_tree_free(stark_tree* tree)
+{
+    if (!tree) return;
+    if (tree->owns) {
+        (void)hipStreamSynchronize(tree->ctx->stream);
+        pool_free(tree->ctx, tree->d, (2 * tree->n - 1) * sizeof(digest));
+    }
+    delete tree;
+}
+
+// ===========================================================================
+// FRI
+// ===========================================================================
+extern "C" size_t stark_fri_num_rounds(size_t domain_length, size_t expansion_factor, size_t num_colinearity_tests)
+{
+    size_t len = domain_length, rounds = 0;
+    while (len > expansion_factor && 4 * num_colinearity_tests < len) {
+        len /= 2;
+        rounds++;
+    }
+    return rounds;
+}
+
+// power tables of omega^-1 covering exponents < N
+static int32_t fold_tables(stark_ctx* ctx, fe omega, size_t N, const PowTables** out)
+{
+    return get_pow_tables(ctx, ctx->F.inverse(omega), N, out);
+}
+
+static fe fold_constant(const HostField& F, fe alpha, fe offset)
+{
+    fe two_inv = F.inverse(fe{2, 0});
+    return F.to_mont(F.mul(F.mul(two_inv, alpha), F.inverse(offset)));
+}
+
+extern "C" int32_t stark_fri_fold_dev(stark_ctx* ctx, const uint64_t* codeword_dev, size_t N,
+                                      const uint64_t alpha[2], const uint64_t offset[2], const uint64_t omega[2],
+                                      uint64_t* out_dev)
+{
+    if (!ctx || !codeword_dev || !alpha || !offset || !omega || !out_dev) return fail(STARK_EARG, "null argument");
+    if (N < 2 || (N & 1)) return fail(STARK_ELENGTH, "codeword length must be even");
+    fe al{alpha[0], alpha[1]}, of{offset[0], offset[1]}, om{omega[0], omega[1]};
+    if (!is_canonical(al) || !is_canonical(of) || !is_canonical(om)) return fail(STARK_EARG, "scalar not reduced modulo p");
+    const PowTables* pt;
+    ST_TRY(fold_tables(ctx, om, N / 2, &pt));
+    FoldArgs a{};
+    a.cw = (const fe*)codeword_dev;
+    a.out = (fe*)out_dev;
+    a.leaf_out = nullptr;
+    a.hi = pt->hi;
+    a.lo = pt->lo;
+    a.c_m = fold_constant(ctx->F, al, of);
+    a.half = N / 2;
+    a.shift = 0;
+    HIP_TRY(launch_fri_fold(a, ctx->stream));
+    return STARK_OK;
+}
+
+extern "C" int32_t stark_fri_fold(stark_ctx* ctx, const uint64_t* codeword, size_t N, const uint64_t alpha[2],
+                                  const uint64_t offset[2], const uint64_t omega[2], uint64_t* out)
+{
+    if (!ctx || !codeword || !out) return fail(STARK_EARG, "null argument");
+    if (N < 2 || (N & 1)) return fail(STARK_ELENGTH, "codeword length must be even");
+    DevBuf in(ctx), ob(ctx);
+    ST_TRY(in.alloc(N * sizeof(fe)));
+    ST_TRY(ob.alloc(N / 2 * sizeof(fe)));
+    HIP_TRY(hipMemcpyAsync(in.p, codeword, N * sizeof(fe), hipMemcpyHostToDevice, ctx->stream));
+    ST_TRY(stark_fri_fold_dev(ctx, (const uint64_t*)in.p, N, alpha, offset, omega, (uint64_t*)ob.p));
+    HIP_TRY(hipMemcpyAsync(out, ob.p, N / 2 * sizeof(fe), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return STARK_OK;
+}
+
+static int32_t fri_commit_impl(stark_ctx* ctx, const fe* cw_src, bool src_is_host, size_t N, const uint64_t offset[2],
+                               const uint64_t omega[2], size_t expansion_factor, size_t num_colinearity_tests,
+                               stark_transcript_cb cb, void* user, stark_fri_layers** layers_out)
+{
+    if (!ctx || !cw_src || !offset || !omega || !cb || !layers_out) return fail(STARK_EARG, "null argument");
+    const size_t rounds = stark_fri_num_rounds(N, expansion_factor, num_colinearity_tests);
+    if (rounds == 0) return fail(STARK_EROUNDS, "Cannot do FRI with less than 1 round");
+    if (log2_exact(N) < 0) return fail(STARK_ENOTPOW2, "length must be power of two");
+    const HostField& F = ctx->F;
+    fe om{omega[0], omega[1]}, of{offset[0], offset[1]};
+    if (!is_canonical(om) || !is_canonical(of)) return fail(STARK_EARG, "scalar not reduced modulo p");
+    // fri.rs:116: omega^(N-1) == omega^-1 at every round; omega^N == 1 implies it for all of them
+    if (fe_is_zero(om) || !fe_eq(F.pow(om, (u128)N - 1), F.inverse(om)))
+        return fail(STARK_EORDER, "error in commit: omega does not have the right order!");
+
+    std::unique_ptr<stark_fri_layers> L(new stark_fri_layers());
+    L->ctx = ctx;
+    size_t total_elems = 0, total_digests = 0;
+    for (size_t r = 0; r < rounds; r++) {
+        L->len.push_back(N >> r);
+        total_elems += N >> r;
+        total_digests += 2 * (N >> r) - 1;
+    }
+    L->cw_bytes = total_elems * sizeof(fe);
+    L->tree_bytes = total_digests * sizeof(digest);
+    void* p = nullptr;
+    ST_TRY(pool_alloc(ctx, L->cw_bytes, &p));
+    L->cw_arena = (fe*)p;
+    int32_t rc = pool_alloc(ctx, L->tree_bytes, &p);
+    if (rc != STARK_OK) {
+        pool_free(ctx, L->cw_arena, L->cw_bytes);
+        return rc;
+    }
+    L->tree_arena = (digest*)p;
+    {
+        fe* c = L->cw_arena;
+        digest* t = L->tree_arena;
+        for (size_t r = 0; r < rounds; r++) {
+            L->cw.push_back(c);
+            L->tree.push_back(t);
+            c += L->len[r];
+            t += 2 * L->len[r] - 1;
+        }
+    }
+    L->roots.resize(rounds);
+
+    auto cleanup = [&](int32_t code) {
+        (void)hipStreamSynchronize(ctx->stream);
+        pool_free(ctx, L->cw_arena, L->cw_bytes);
+        pool_free(ctx, L->tree_arena, L->tree_bytes);
+        return code;
+    };
+#define FRI_HIP(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return cleanup(fail(STARK_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_))); \
+    } while (0)
+
+    const PowTables* pt;
+    rc = fold_tables(ctx, om, N / 2, &pt);
+    if (rc != STARK_OK) return cleanup(rc);
+
+    FRI_HIP(hipMemcpyAsync(L->cw[0], cw_src, N * sizeof(fe),
+                           src_is_host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, ctx->stream));   // fri.rs:130
+    FRI_HIP(launch_leaf_hash(L->cw[0], L->tree[0], N, ctx->stream));
+    fe offset_r = of;
+    for (size_t r = 0; r < rounds; r++) {
+        const size_t n = L->len[r];
+        FRI_HIP(launch_merkle_reduce(L->tree[r], n, ctx->stream));                                     // fri.rs:119
+        FRI_HIP(hipMemcpyAsync(ctx->pinned, L->tree[r] + (2 * n - 2), 32, hipMemcpyDeviceToHost, ctx->stream));
+        FRI_HIP(hipStreamSynchronize(ctx->stream));
+        memcpy(L->roots[r].data(), ctx->pinned, 32);
+        const bool last = (r == rounds - 1);
+        uint64_t alpha_raw[2] = {0, 0};
+        if (cb(user, (uint32_t)r, last ? 1 : 0, L->roots[r].data(), alpha_raw) != 0)                   // fri.rs:120,126-127
+            return cleanup(fail(STARK_ECALLBACK, "transcript callback failed"));
+        if (last) break;                                                                               // fri.rs:123
+        fe alpha{alpha_raw[0], alpha_raw[1]};
+        if (!is_canonical(alpha)) return cleanup(fail(STARK_EARG, "alpha not reduced modulo p"));
+        FoldArgs a{};
+        a.cw = L->cw[r];
+        a.out = L->cw[r + 1];
+        a.leaf_out = L->tree[r + 1];
+        a.hi = pt->hi;
+        a.lo = pt->lo;
+        a.c_m = fold_constant(F, alpha, offset_r);
+        a.half = n / 2;
+        a.shift = (uint32_t)r;
+        FRI_HIP(launch_fri_fold(a, ctx->stream));                                                      // fri.rs:133-139
+        offset_r = F.mul(offset_r, offset_r);                                                          // fri.rs:142
+    }
+#undef FRI_HIP
+    *layers_out = L.release();
+    return STARK_OK;
+}
+
+extern "C" int32_t stark_fri_commit_dev(stark_ctx* ctx, const uint64_t* codeword_dev, size_t N,
+                                        const uint64_t offset[2], const uint64_t omega[2], size_t expansion_factor,
+                                        size_t num_colinearity_tests, stark_transcript_cb cb, void* user,
+                                        stark_fri_layers** layers_out)
+{
+    return fri_commit_impl(ctx, (const fe*)codeword_dev, false, N, offset, omega, expansion_factor,
+                           num_colinearity_tests, cb, user, layers_out);
+}
+
+extern "C" int32_t stark_fri_commit(stark_ctx* ctx, const uint64_t* codeword, size_t N, const uint64_t offset[2],
+                                    const uint64_t omega[2], size_t expansion_factor, size_t num_colinearity_tests,
+                                    stark_transcript_cb cb, void* user, stark_fri_layers** layers_out)
+{
+    return fri_commit_impl(ctx, (const fe*)codeword, true, N, offset, omega, expansion_factor,
+                           num_colinearity_tests, cb, user, layers_out);
+}
+
+extern "C" size_t stark_fri_layers_count(const stark_fri_layers* l) { return l ? l->len.size() : 0; }
+
+extern "C" size_t stark_fri_layer_len(const stark_fri_layers* l, size_t layer)
+{
+    return (l && layer < l->len.size()) ? l->len[layer] : 0;
+}
+
+extern "C" int32_t stark_fri_layer_root(const stark_fri_layers* l, size_t layer, uint8_t root[32])
+{
+    if (!l || !root || layer >= l->len.size()) return fail(STARK_EARG, "bad layer");
+    memcpy(root, l->roots[layer].data(), 32);
+    return STARK_OK;
+}
+
+extern "C" int32_t stark_fri_layer_download(stark_fri_layers* l, size_t layer, uint64_t* out)
+{
+    if (!l || !out || layer >= l->len.size()) return fail(STARK_EARG, "bad layer");
+    HIP_TRY(hipMemcpyAsync(out, l->cw[layer], l->len[layer] * sizeof(fe), hipMemcpyDeviceToHost, l->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(l->ctx->stream));
+    return STARK_OK;
+}
+
+extern "C" int32_t stark_fri_layer_read(stark_fri_layers* l, size_t layer, const uint64_t* indices, size_t count,
+                                        uint64_t* out)
+{
+    if (!l || !indices || !out || layer >= l->len.size()) return fail(STARK_EARG, "bad layer");
+    if (count == 0) return STARK_OK;
+    for (size_t i = 0; i < count; i++)
+        if (indices[i] >= l->len[layer]) return fail(STARK_EINDEX, "codeword index out of range");
+    stark_ctx* ctx = l->ctx;
+    DevBuf di(ctx), dov(ctx);
+    ST_TRY(di.alloc(count * sizeof(uint64_t)));
+    ST_TRY(dov.alloc(count * sizeof(fe)));
+    HIP_TRY(hipMemcpyAsync(di.p, indices, count * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(launch_gather_fe(l->cw[layer], (const uint64_t*)di.p, (fe*)dov.p, count, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(out, dov.p, count * sizeof(fe), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return STARK_OK;
+}
+
+extern "C" int32_t stark_fri_layer_open(stark_fri_layers* l, size_t layer, size_t index, uint8_t* path_out,
+                                        size_t* depth_out)
+{
+    if (!l || !path_out || layer >= l->len.size()) return fail(STARK_EARG, "bad layer");
+    return tree_open(l->ctx, l->tree[layer], l->len[layer], index, path_out, depth_out);
+}
+
+extern "C" void stark_fri_layers_free(stark_fri_layers* l)
+{
+    if (!l) return;
+    (void)hipStreamSynchronize(l->ctx->stream);
+    pool_free(l->ctx, l->cw_arena, l->cw_bytes);
+    pool_free(l->ctx, l->tree_arena, l->tree_bytes);
+    delete l;
+}

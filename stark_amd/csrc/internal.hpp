@@ -1,0 +1,89 @@
+// Internal launcher interface between the C-ABI layer (api.cpp) and the kernel
+// translation units.  Not part of the public ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "blake2b.hpp"
+#include "field.hpp"
+
+namespace starkk {
+
+using starkf::fe;
+using starkh::digest;
+
+constexpr int TILE_ELEMS = 4096;      // elements per workgroup tile
+constexpr int TILE_THREADS = 256;
+constexpr int SMALL_MAX_LOG = 12;     // n <= 4096: one workgroup per transform
+constexpr int MAX_PASSES = 4;
+
+// One global pass of the multi-pass NTT.  n = R_0 * R_1 * ... * R_{P-1}; pass q
+// transforms digit q (radix R_q = 2^r, stride S_q = prod_{u>q} R_u).
+struct PassArgs {
+    const fe* src;
+    fe* dst;
+    const fe* tw16;        // omega_16^i, i<8 (Montgomery form)
+    const fe* tw256;       // omega_256^i, i<256 (Montgomery form)
+    const fe* hi;          // omega_n^(i << h), i < n >> h (Montgomery form)
+    const fe* lo;          // omega_n^i, i < 2^h (Montgomery form; times n^-1 for the inverse)
+    const fe* twist_hi;    // s^(256 i) (Montgomery form), first pass of a coset transform
+    const fe* twist_lo;    // s^i, i<256
+    uint64_t src_batch_stride;   // elements between consecutive transforms of a batch
+    uint64_t dst_batch_stride;
+    uint64_t n_src;        // valid source elements (first pass zero-fills the rest)
+    uint32_t log_n;
+    uint32_t log_s;        // log2 S_q
+    uint32_t r;            // log2 R_q (5..8)
+    uint32_t h;            // log2 of the last radix
+    uint32_t nprev;        // q
+    uint32_t rprev[MAX_PASSES];   // log2 R_u, u < q
+};
+
+enum PassMode { PASS_FIRST = 0, PASS_MIDDLE = 1, PASS_LAST = 2 };
+
+hipError_t launch_ntt_pass(const PassArgs& a, PassMode mode, bool twist, uint32_t n_batch, hipStream_t s);
+
+struct SmallArgs {
+    const fe* src;
+    fe* dst;
+    const fe* tw;          // omega_n^i, i < n/2 (Montgomery form)
+    const fe* twist_hi;
+    const fe* twist_lo;
+    fe scale_m;            // n^-1 in Montgomery form (inverse only)
+    uint64_t src_batch_stride, dst_batch_stride, n_src;
+    uint32_t log_n;
+    uint32_t has_scale, has_twist;
+};
+hipError_t launch_ntt_small(const SmallArgs& a, uint32_t n_batch, hipStream_t s);
+
+hipError_t launch_vec_mul(const fe* a, const fe* b, fe* out, size_t n, fe r2, hipStream_t s);
+
+// --- Merkle / FRI -----------------------------------------------------------
+// Tree storage: levels concatenated, leaf digests first; level l holds n>>l
+// digests at digest offset 2n - (2n >> l); the root is digest 2n-2.
+hipError_t launch_leaf_hash(const fe* elems, digest* level0, size_t n, hipStream_t s);
+hipError_t launch_leaf_hash_bytes(const uint8_t* flat, const uint64_t* offsets, digest* level0, size_t n,
+                                  hipStream_t s);
+// Reduce a level of m digests (power of two) to the root, writing every level
+// contiguously after it.
+hipError_t launch_merkle_reduce(digest* level, size_t m, hipStream_t s);
+
+struct FoldArgs {
+    const fe* cw;          // N elements
+    fe* out;               // N/2 elements
+    digest* leaf_out;      // optional: leaf digests of out (level 0 of its tree)
+    const fe* hi;          // w^-(i << 8), Montgomery form
+    const fe* lo;          // w^-i, i<256, Montgomery form
+    fe c_m;                // 2^-1 * alpha * offset^-1, Montgomery form
+    uint64_t half;         // N/2
+    uint32_t shift;        // omega of this layer = w^(2^shift)
+};
+hipError_t launch_fri_fold(const FoldArgs& a, hipStream_t s);
+
+// Authentication path of `index` (merkle.rs:54-93): depth digests, sibling leaf first.
+hipError_t launch_merkle_open(const digest* tree, size_t n, size_t index, digest* path_out, hipStream_t s);
+
+hipError_t launch_gather_fe(const fe* src, const uint64_t* idx, fe* out, size_t count, hipStream_t s);
+
+}  // namespace starkk

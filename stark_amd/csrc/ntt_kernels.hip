@@ -1,0 +1,316 @@
+// NTT kernels for gfx950 (reference semantics: src/modules/ntt.rs:25-71 --
+// natural order in, natural order out, X[k] = sum_j x[j] w^(jk)).
+//
+// Large transforms are a mixed-radix decimation-in-time factorisation
+// n = R_0 R_1 ... R_{P-1} (R_q = 2^5..2^8) run as P global passes.  A workgroup
+// owns a tile of 4096 elements = R_q sub-transform points x C columns, held in
+// registers (16 elements per thread).  Each pass is two register rounds
+// (radix R_q/16, then radix 16) with one exchange through LDS.  Bit reversal
+// never happens as a data movement: digit reversal is folded into the pass
+// addressing, and the last pass writes its result transposed into natural
+// order.  Twiddles are read from small HBM/L2-resident tables in Montgomery
+// form; the coset shift of a low-degree extension is applied to the loaded
+// coefficients of the first pass, and the padding zeros are never read.
+#include <hip/hip_runtime.h>
+
+#include "internal.hpp"
+
+namespace starkk {
+
+using namespace starkf;
+
+__device__ __forceinline__ constexpr int brev_c(int k, int bits)
+{
+    int r = 0;
+    for (int i = 0; i < bits; i++) r |= ((k >> i) & 1) << (bits - 1 - i);
+    return r;
+}
+
+// In-register decimation-in-frequency transform of M = 2^LOGM values at
+// v[BASE .. BASE+M): natural order in, bit-reversed order out (output k sits in
+// register BASE + brev(k)).  tw16[i] = w_16^i in Montgomery form; the index is
+// a compile-time constant after unrolling, so the loads are scalar.
+template <int LOGM, int BASE>
+__device__ __forceinline__ void ntt_dif_reg(fe (&v)[16], const fe* __restrict__ tw16)
+{
+    constexpr int M = 1 << LOGM;
+#pragma unroll
+    for (int lg = LOGM; lg >= 1; lg--) {
+        const int len = 1 << lg;
+        const int half = len >> 1;
+#pragma unroll
+        for (int s = 0; s < M; s += len) {
+#pragma unroll
+            for (int j = 0; j < half; j++) {
+                fe a = v[BASE + s + j];
+                fe b = v[BASE + s + j + half];
+                v[BASE + s + j] = fe_add(a, b);
+                fe d = fe_sub(a, b);
+                const int e = j * (16 / len);
+                v[BASE + s + j + half] = (e == 0) ? d : mont_mul(d, tw16[e]);
+            }
+        }
+    }
+}
+
+template <int LOGM, int G>
+struct RoundOne {
+    __device__ __forceinline__ static void run(fe (&v)[16], const fe* __restrict__ tw16)
+    {
+        ntt_dif_reg<LOGM, (G - 1) * (1 << LOGM)>(v, tw16);
+        RoundOne<LOGM, G - 1>::run(v, tw16);
+    }
+};
+template <int LOGM>
+struct RoundOne<LOGM, 0> {
+    __device__ __forceinline__ static void run(fe (&)[16], const fe* __restrict__) {}
+};
+
+// memory prefix (k_0 most significant) -> K = k_0 + R_0 k_1 + ...
+__device__ __forceinline__ uint32_t prefix_to_k(uint32_t pre, const PassArgs& a)
+{
+    uint32_t K = 0;
+    uint32_t below = 0;
+    for (uint32_t u = 0; u < a.nprev; u++) below += a.rprev[u];
+    for (int u = (int)a.nprev - 1; u >= 0; u--) {
+        below -= a.rprev[u];
+        uint32_t d = pre & ((1u << a.rprev[u]) - 1);
+        pre >>= a.rprev[u];
+        K |= d << below;
+    }
+    return K;
+}
+
+// K = k_0 + R_0 k_1 + ... -> memory prefix
+__device__ __forceinline__ uint32_t k_to_prefix(uint32_t K, const PassArgs& a)
+{
+    uint32_t pre = 0;
+    for (uint32_t u = 0; u < a.nprev; u++) {
+        uint32_t d = K & ((1u << a.rprev[u]) - 1);
+        K >>= a.rprev[u];
+        pre = (pre << a.rprev[u]) | d;
+    }
+    return pre;
+}
+
+// RA = log2(R) - 4.  MODE: PASS_FIRST (optional coset twist, zero fill),
+// PASS_MIDDLE (twiddle from hi table), PASS_LAST (rows contiguous, twiddle
+// hi*lo, transposed store to natural order).
+template <int RA, int MODE, bool TWIST>
+__global__ __launch_bounds__(TILE_THREADS) void ntt_pass_kernel(PassArgs a)
+{
+    constexpr int M1 = 1 << RA;          // round-1 radix
+    constexpr int G1 = 16 / M1;          // round-1 groups per thread
+    constexpr int R = 16 * M1;           // sub-transform size of this pass
+    constexpr int LOGC = 8 - RA;
+    constexpr int C = 1 << LOGC;         // columns (rows in PASS_LAST) per tile
+    constexpr int PITCH = (MODE == PASS_LAST) ? (C + 1) : C;
+    constexpr int TWSHIFT = 8 - (RA + 4);
+
+    __shared__ fe lds[R * PITCH];
+    __shared__ fe s_tw256[256];
+
+    const int t = threadIdx.x;
+    const fe* __restrict__ src = a.src + (uint64_t)blockIdx.y * a.src_batch_stride;
+    fe* __restrict__ dst = a.dst + (uint64_t)blockIdx.y * a.dst_batch_stride;
+    const fe* __restrict__ tw16 = a.tw16;
+
+    s_tw256[t] = a.tw256[t];
+
+    fe v[16];
+
+    // ---- load + pass twiddle -------------------------------------------------
+#pragma unroll
+    for (int g = 0; g < G1; g++) {
+        const int q1 = t + TILE_THREADS * g;
+        if constexpr (MODE == PASS_LAST) {
+            const int c = q1 >> 4, jb = q1 & 15;
+            const uint32_t b = blockIdx.x * C + c;                 // low part of the output index
+            const uint64_t row = (uint64_t)k_to_prefix(b, a) << a.r;
+#pragma unroll
+            for (int ja = 0; ja < M1; ja++) {
+                const uint32_t j = ja * 16 + jb;
+                fe x = src[row + j];
+                const uint32_t E = j * b;                          // < n
+                fe w = mont_mul(a.hi[E >> a.h], a.lo[E & (R - 1)]);
+                v[g * M1 + ja] = mont_mul(x, w);
+            }
+        } else {
+            const int jb = q1 >> LOGC, c = q1 & (C - 1);
+            const uint64_t f = (uint64_t)blockIdx.x * C + c;       // flat column of this pass
+            const uint32_t pre = (uint32_t)(f >> a.log_s);
+            const uint64_t col = f & (((uint64_t)1 << a.log_s) - 1);
+            const uint64_t base = ((uint64_t)pre << (a.r + a.log_s)) + col;
+            uint32_t ks = 0;
+            if constexpr (MODE == PASS_MIDDLE) ks = prefix_to_k(pre, a) << (a.log_s - a.h);
+#pragma unroll
+            for (int ja = 0; ja < M1; ja++) {
+                const uint32_t j = ja * 16 + jb;
+                const uint64_t idx = base + ((uint64_t)j << a.log_s);
+                fe x;
+                if constexpr (MODE == PASS_FIRST) {
+                    x = fe_zero();
+                    if (idx < a.n_src) {
+                        x = src[idx];
+                        if constexpr (TWIST)
+                            x = mont_mul(mont_mul(x, a.twist_lo[idx & 255]), a.twist_hi[idx >> 8]);
+                    }
+                } else {
+                    x = mont_mul(src[idx], a.hi[j * ks]);
+                }
+                v[g * M1 + ja] = x;
+            }
+        }
+    }
+
+    __syncthreads();            // s_tw256 staged
+
+    // ---- round 1: radix M1 over ja ---------------------------------------------
+    RoundOne<RA, G1>::run(v, tw16);
+
+    // ---- inner twiddle w_R^(jb*ka), exchange through LDS -----------------------
+#pragma unroll
+    for (int g = 0; g < G1; g++) {
+        const int q1 = t + TILE_THREADS * g;
+        int jb, c;
+        if constexpr (MODE == PASS_LAST) { c = q1 >> 4; jb = q1 & 15; }
+        else { jb = q1 >> LOGC; c = q1 & (C - 1); }
+#pragma unroll
+        for (int ka = 0; ka < M1; ka++) {
+            const int reg = g * M1 + brev_c(ka, RA);
+            fe x = v[reg];
+            if (ka != 0) x = mont_mul(x, s_tw256[(jb * ka) << TWSHIFT]);
+            lds[(ka * 16 + jb) * PITCH + c] = x;
+        }
+    }
+
+    __syncthreads();
+
+    // ---- round 2: radix 16 over jb ----------------------------------------------
+    const int ka2 = t >> LOGC, c2 = t & (C - 1);
+#pragma unroll
+    for (int jb = 0; jb < 16; jb++) v[jb] = lds[(ka2 * 16 + jb) * PITCH + c2];
+
+    ntt_dif_reg<4, 0>(v, tw16);
+
+    // ---- store ----------------------------------------------------------------
+    if constexpr (MODE == PASS_LAST) {
+        const uint64_t b = (uint64_t)blockIdx.x * C + c2;
+        const uint32_t sh = a.log_n - a.r;
+#pragma unroll
+        for (int kb = 0; kb < 16; kb++) {
+            const uint64_t k = ka2 + M1 * kb;
+            dst[(k << sh) + b] = v[brev_c(kb, 4)];
+        }
+    } else {
+        const uint64_t f = (uint64_t)blockIdx.x * C + c2;
+        const uint64_t pre = f >> a.log_s;
+        const uint64_t col = f & (((uint64_t)1 << a.log_s) - 1);
+        const uint64_t base = (pre << (a.r + a.log_s)) + col;
+#pragma unroll
+        for (int kb = 0; kb < 16; kb++) {
+            const uint64_t k = ka2 + M1 * kb;
+            dst[base + (k << a.log_s)] = v[brev_c(kb, 4)];
+        }
+    }
+}
+
+template <int RA, int MODE, bool TWIST>
+static hipError_t launch_one(const PassArgs& a, uint32_t n_batch, hipStream_t s)
+{
+    dim3 grid((uint32_t)(((uint64_t)1 << a.log_n) / TILE_ELEMS), n_batch, 1);
+    hipLaunchKernelGGL((ntt_pass_kernel<RA, MODE, TWIST>), grid, dim3(TILE_THREADS), 0, s, a);
+    return hipGetLastError();
+}
+
+template <int RA>
+static hipError_t launch_ra(const PassArgs& a, PassMode mode, bool twist, uint32_t n_batch, hipStream_t s)
+{
+    switch (mode) {
+    case PASS_FIRST:
+        return twist ? launch_one<RA, PASS_FIRST, true>(a, n_batch, s)
+                     : launch_one<RA, PASS_FIRST, false>(a, n_batch, s);
+    case PASS_MIDDLE: return launch_one<RA, PASS_MIDDLE, false>(a, n_batch, s);
+    case PASS_LAST: return launch_one<RA, PASS_LAST, false>(a, n_batch, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_ntt_pass(const PassArgs& a, PassMode mode, bool twist, uint32_t n_batch, hipStream_t s)
+{
+    if (a.log_n <= (uint32_t)SMALL_MAX_LOG || a.log_n > 30) return hipErrorInvalidValue;
+    switch (a.r) {
+    case 5: return launch_ra<1>(a, mode, twist, n_batch, s);
+    case 6: return launch_ra<2>(a, mode, twist, n_batch, s);
+    case 7: return launch_ra<3>(a, mode, twist, n_batch, s);
+    case 8: return launch_ra<4>(a, mode, twist, n_batch, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+// ---------------------------------------------------------------------------
+// n <= 4096: the whole transform lives in one workgroup's LDS.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(TILE_THREADS) void ntt_small_kernel(SmallArgs a)
+{
+    __shared__ fe s[1 << SMALL_MAX_LOG];
+    const uint32_t n = 1u << a.log_n;
+    const fe* __restrict__ src = a.src + (uint64_t)blockIdx.x * a.src_batch_stride;
+    fe* __restrict__ dst = a.dst + (uint64_t)blockIdx.x * a.dst_batch_stride;
+    for (uint32_t i = threadIdx.x; i < n; i += TILE_THREADS) {
+        fe x = fe_zero();
+        if (i < a.n_src) {
+            x = src[i];
+            if (a.has_twist) x = mont_mul(mont_mul(x, a.twist_lo[i & 255]), a.twist_hi[i >> 8]);
+        }
+        const uint32_t rev = a.log_n ? (__brev(i) >> (32 - a.log_n)) : 0;
+        s[rev] = x;
+    }
+    __syncthreads();
+    for (uint32_t lg = 1; lg <= a.log_n; lg++) {
+        const uint32_t half = 1u << (lg - 1);
+        const uint32_t tstep = a.log_n - lg;                   // w_len^j = w_n^(j << tstep)
+        for (uint32_t b = threadIdx.x; b < (n >> 1); b += TILE_THREADS) {
+            const uint32_t j = b & (half - 1);
+            const uint32_t i0 = ((b >> (lg - 1)) << lg) + j;
+            fe u = s[i0];
+            fe w = s[i0 + half];
+            if (j) w = mont_mul(w, a.tw[j << tstep]);
+            s[i0] = fe_add(u, w);
+            s[i0 + half] = fe_sub(u, w);
+        }
+        __syncthreads();
+    }
+    for (uint32_t i = threadIdx.x; i < n; i += TILE_THREADS) {
+        fe x = s[i];
+        if (a.has_scale) x = mont_mul(x, a.scale_m);
+        dst[i] = x;
+    }
+}
+
+hipError_t launch_ntt_small(const SmallArgs& a, uint32_t n_batch, hipStream_t s)
+{
+    if (a.log_n > (uint32_t)SMALL_MAX_LOG) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(ntt_small_kernel, dim3(n_batch), dim3(TILE_THREADS), 0, s, a);
+    return hipGetLastError();
+}
+
+// Pointwise canonical product (ntt.rs:125-127).  r2 = 2^256 mod p.
+__global__ void vec_mul_kernel(const fe* __restrict__ x, const fe* __restrict__ y, fe* __restrict__ out,
+                               size_t n, fe r2)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += step) out[i] = mont_mul(mont_mul(x[i], y[i]), r2);
+}
+
+hipError_t launch_vec_mul(const fe* a, const fe* b, fe* out, size_t n, fe r2, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(vec_mul_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, a, b, out, n, r2);
+    return hipGetLastError();
+}
+
+}  // namespace starkk

@@ -1,0 +1,264 @@
+"""Thin Python handle on the C ABI (include/stark_hip.h).
+
+Host-path methods take numpy arrays of shape (n, 2) uint64 ({lo, hi} per field
+element); *_dev methods take device pointers (e.g. torch tensors of dtype int64
+and shape (n, 2), through .data_ptr()).  PyTorch is only used by callers for
+device memory and streams; nothing here imports it."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Callable, List, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+
+ERR = {1: "ENOTPOW2", 2: "ETOOLARGE", 3: "ELENGTH", 4: "EINDEX", 5: "EROUNDS", 6: "EORDER", 7: "EARG", 8: "EHIP",
+       9: "ENOMEM", 10: "ECALLBACK"}
+
+
+class StarkError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"{ERR.get(code, code)}: {msg}")
+        self.code = code
+        self.message = msg
+
+
+def _fe(v: int):
+    return (C.c_uint64 * 2)(v & 0xFFFFFFFFFFFFFFFF, v >> 64)
+
+
+def _ptr(x) -> int:
+    """numpy array -> host pointer; int -> as is; object with data_ptr() -> device pointer."""
+    if isinstance(x, np.ndarray):
+        assert x.flags["C_CONTIGUOUS"]
+        return x.ctypes.data
+    if hasattr(x, "data_ptr"):
+        return x.data_ptr()
+    return int(x)
+
+
+def _as_fe_array(a) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    assert a.ndim >= 1 and a.shape[-1] == 2, "field vectors are (..., 2) uint64"
+    return a
+
+
+class Tree:
+    """A Merkle tree retained on the device (merkle.rs)."""
+
+    def __init__(self, ctx: "Context", handle):
+        self.ctx, self.h = ctx, handle
+
+    @property
+    def num_leaves(self) -> int:
+        return self.ctx.lib.stark_tree_num_leaves(self.h)
+
+    def open(self, index: int) -> List[bytes]:
+        buf = (C.c_uint8 * (32 * 64))()
+        depth = C.c_size_t(0)
+        self.ctx._chk(self.ctx.lib.stark_merkle_open(self.h, index, buf, C.byref(depth)))
+        raw = bytes(buf)
+        return [raw[32 * i:32 * i + 32] for i in range(depth.value)]
+
+    def download(self) -> np.ndarray:
+        n = self.num_leaves
+        out = np.empty((2 * n - 1, 32), dtype=np.uint8)
+        self.ctx._chk(self.ctx.lib.stark_tree_download(self.h, out.ctypes.data))
+        return out
+
+    def free(self):
+        if self.h:
+            self.ctx.lib.stark_tree_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class FriLayers:
+    """Codewords and trees of one Fri::commit, resident on the device."""
+
+    def __init__(self, ctx: "Context", handle):
+        self.ctx, self.h = ctx, handle
+
+    def __len__(self):
+        return self.ctx.lib.stark_fri_layers_count(self.h)
+
+    def layer_len(self, i: int) -> int:
+        return self.ctx.lib.stark_fri_layer_len(self.h, i)
+
+    def root(self, i: int) -> bytes:
+        buf = (C.c_uint8 * 32)()
+        self.ctx._chk(self.ctx.lib.stark_fri_layer_root(self.h, i, buf))
+        return bytes(buf)
+
+    def download(self, i: int) -> np.ndarray:
+        out = np.empty((self.layer_len(i), 2), dtype=np.uint64)
+        self.ctx._chk(self.ctx.lib.stark_fri_layer_download(self.h, i, out.ctypes.data))
+        return out
+
+    def read(self, i: int, indices: Sequence[int]) -> np.ndarray:
+        idx = np.asarray(indices, dtype=np.uint64)
+        out = np.empty((len(idx), 2), dtype=np.uint64)
+        self.ctx._chk(self.ctx.lib.stark_fri_layer_read(
+            self.h, i, idx.ctypes.data_as(_lib.u64p), len(idx), out.ctypes.data))
+        return out
+
+    def open(self, i: int, index: int) -> List[bytes]:
+        buf = (C.c_uint8 * (32 * 64))()
+        depth = C.c_size_t(0)
+        self.ctx._chk(self.ctx.lib.stark_fri_layer_open(self.h, i, index, buf, C.byref(depth)))
+        raw = bytes(buf)
+        return [raw[32 * k:32 * k + 32] for k in range(depth.value)]
+
+    def free(self):
+        if self.h:
+            self.ctx.lib.stark_fri_layers_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Context:
+    def __init__(self, device: int = 0):
+        self.lib = _lib.load()
+        h = C.c_void_p()
+        rc = self.lib.stark_ctx_create(device, C.byref(h))
+        if rc:
+            raise StarkError(rc, self.lib.stark_last_error().decode())
+        self.h = h
+        self.device = device
+
+    def _chk(self, rc: int):
+        if rc:
+            raise StarkError(rc, self.lib.stark_last_error().decode())
+
+    def close(self):
+        if self.h:
+            self.lib.stark_ctx_destroy(self.h)
+            self.h = None
+
+    def set_stream(self, hip_stream: Optional[int]):
+        self._chk(self.lib.stark_ctx_set_stream(self.h, hip_stream))
+
+    def synchronize(self):
+        self._chk(self.lib.stark_ctx_synchronize(self.h))
+
+    # ---- NTT ------------------------------------------------------------
+    def ntt(self, data, inverse: bool = False) -> np.ndarray:
+        a = _as_fe_array(data).copy()
+        self._chk(self.lib.stark_ntt(self.h, a.ctypes.data, a.shape[0], int(inverse)))
+        return a
+
+    def ntt_batch(self, data, inverse: bool = False) -> np.ndarray:
+        a = _as_fe_array(data).copy()
+        assert a.ndim == 3
+        self._chk(self.lib.stark_ntt_batch(self.h, a.ctypes.data, a.shape[1], a.shape[0], a.shape[1], int(inverse)))
+        return a
+
+    def ntt_dev(self, dptr, n: int, inverse: bool = False, n_cols: int = 1, col_stride: Optional[int] = None):
+        self._chk(self.lib.stark_ntt_batch_dev(self.h, _ptr(dptr), n, n_cols, col_stride or n, int(inverse)))
+
+    def coset_lde_batch(self, coeffs, n_out: int, offset: int) -> np.ndarray:
+        a = _as_fe_array(coeffs)
+        if a.ndim == 2:
+            a = a[None]
+        n_cols, n_coeffs = a.shape[0], a.shape[1]
+        out = np.empty((n_cols, n_out, 2), dtype=np.uint64)
+        self._chk(self.lib.stark_coset_lde_batch(self.h, a.ctypes.data, n_coeffs, n_coeffs, n_cols, n_out,
+                                                 _fe(offset), out.ctypes.data, n_out))
+        return out
+
+    def coset_lde_batch_dev(self, coeffs_ptr, n_coeffs: int, coeff_stride: int, n_cols: int, n_out: int,
+                            offset: int, out_ptr, out_stride: int):
+        self._chk(self.lib.stark_coset_lde_batch_dev(self.h, _ptr(coeffs_ptr), n_coeffs, coeff_stride, n_cols,
+                                                     n_out, _fe(offset), _ptr(out_ptr), out_stride))
+
+    def vec_mul(self, a, b) -> np.ndarray:
+        a, b = _as_fe_array(a), _as_fe_array(b)
+        assert a.shape == b.shape
+        out = np.empty_like(a)
+        self._chk(self.lib.stark_vec_mul(self.h, a.ctypes.data, b.ctypes.data, out.ctypes.data, a.shape[0]))
+        return out
+
+    # ---- Merkle -----------------------------------------------------------
+    def merkle_commit_fe(self, elems, keep_tree: bool = False):
+        a = _as_fe_array(elems)
+        root = (C.c_uint8 * 32)()
+        th = C.c_void_p()
+        self._chk(self.lib.stark_merkle_commit_fe(self.h, a.ctypes.data, a.shape[0], root,
+                                                  C.byref(th) if keep_tree else None))
+        return (bytes(root), Tree(self, th)) if keep_tree else bytes(root)
+
+    def merkle_commit_fe_dev(self, dptr, n: int, keep_tree: bool = False):
+        root = (C.c_uint8 * 32)()
+        th = C.c_void_p()
+        self._chk(self.lib.stark_merkle_commit_fe_dev(self.h, _ptr(dptr), n, root,
+                                                      C.byref(th) if keep_tree else None))
+        return (bytes(root), Tree(self, th)) if keep_tree else bytes(root)
+
+    def merkle_commit_bytes(self, leaves: Sequence[bytes], keep_tree: bool = False):
+        flat = np.frombuffer(b"".join(leaves) or b"\0", dtype=np.uint8).copy()
+        offs = np.zeros(len(leaves) + 1, dtype=np.uint64)
+        if leaves:
+            offs[1:] = np.cumsum([len(l) for l in leaves])
+        root = (C.c_uint8 * 32)()
+        th = C.c_void_p()
+        self._chk(self.lib.stark_merkle_commit_bytes(self.h, flat.ctypes.data, offs.ctypes.data, len(leaves), root,
+                                                     C.byref(th) if keep_tree else None))
+        return (bytes(root), Tree(self, th)) if keep_tree else bytes(root)
+
+    # ---- FRI --------------------------------------------------------------
+    def fri_fold(self, codeword, alpha: int, offset: int, omega: int) -> np.ndarray:
+        a = _as_fe_array(codeword)
+        out = np.empty((a.shape[0] // 2, 2), dtype=np.uint64)
+        self._chk(self.lib.stark_fri_fold(self.h, a.ctypes.data, a.shape[0], _fe(alpha), _fe(offset), _fe(omega),
+                                          out.ctypes.data))
+        return out
+
+    def fri_fold_dev(self, cw_ptr, n: int, alpha: int, offset: int, omega: int, out_ptr):
+        self._chk(self.lib.stark_fri_fold_dev(self.h, _ptr(cw_ptr), n, _fe(alpha), _fe(offset), _fe(omega),
+                                              _ptr(out_ptr)))
+
+    def fri_num_rounds(self, domain_length: int, expansion_factor: int, num_colinearity_tests: int) -> int:
+        return self.lib.stark_fri_num_rounds(domain_length, expansion_factor, num_colinearity_tests)
+
+    def fri_commit(self, codeword, offset: int, omega: int, expansion_factor: int, num_colinearity_tests: int,
+                   transcript: Callable[[int, bool, bytes], Optional[int]], n: Optional[int] = None) -> FriLayers:
+        """transcript(round, last, root) -> alpha (int) for every round but the last.
+        `codeword` is a numpy array (host path) or a device pointer / tensor (then pass n)."""
+        err: List[BaseException] = []
+
+        def _cb(_user, rnd, last, root_p, alpha_out):
+            try:
+                root = bytes(root_p[i] for i in range(32))
+                alpha = transcript(int(rnd), bool(last), root)
+                if not last:
+                    alpha_out[0] = alpha & 0xFFFFFFFFFFFFFFFF
+                    alpha_out[1] = alpha >> 64
+                return 0
+            except BaseException as e:  # noqa: BLE001 - must not unwind through C
+                err.append(e)
+                return 1
+
+        cb = _lib.TRANSCRIPT_CB(_cb)
+        lh = C.c_void_p()
+        if isinstance(codeword, np.ndarray):
+            a = _as_fe_array(codeword)
+            rc = self.lib.stark_fri_commit(self.h, a.ctypes.data, a.shape[0], _fe(offset), _fe(omega),
+                                           expansion_factor, num_colinearity_tests, cb, None, C.byref(lh))
+        else:
+            rc = self.lib.stark_fri_commit_dev(self.h, _ptr(codeword), n, _fe(offset), _fe(omega),
+                                               expansion_factor, num_colinearity_tests, cb, None, C.byref(lh))
+        if err:
+            raise err[0]
+        self._chk(rc)
+        return FriLayers(self, lh)

@@ -1,0 +1,35 @@
+"""CPU-only checks of the C-ABI library: it loads, exports every symbol that
+include/stark_hip.h declares, and the ctypes table mirrors the header."""
+import os
+import re
+
+from stark_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_functions():
+    text = open(os.path.join(ROOT, "include", "stark_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = re.findall(r"\b(stark_[a-z0-9_]+)\s*\(", text)
+    # drop the callback typedef name
+    return sorted(set(n for n in names if n != "stark_transcript_cb"))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    names = _header_functions()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in stark_hip.h but not exported"
+
+
+def test_ctypes_table_matches_header():
+    assert sorted(_lib.SIGNATURES) == _header_functions()
+
+
+def test_num_rounds_is_host_only():
+    lib = _lib.load()
+    assert lib.stark_fri_num_rounds(1 << 24, 4, 17) == 18
+    assert lib.stark_fri_num_rounds(256, 4, 17) == 2
+    assert lib.stark_fri_num_rounds(4, 4, 1) == 0

@@ -1,0 +1,324 @@
+"""Parity of the HIP library (through the C ABI) with the CPU restatements.
+Bit-exact everywhere: all results are canonical integers, digests or bytes."""
+import hashlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import oracle_c as oc          # noqa: E402
+import stark_oracle as so      # noqa: E402
+
+P, G = so.P, so.GENERATOR
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from stark_amd import Context
+    c = Context(0)
+    yield c
+    c.close()
+
+
+def _edge_vector(n, seed):
+    x = oc.splitmix(n, seed)
+    edge = [0, 1, P - 1, 2, (1 << 64) - 1, 1 << 64, (1 << 96) + 5, P - 2]
+    for i, v in enumerate(edge[: max(0, min(len(edge), n - 1))]):
+        x[(i * 7 + 1) % n] = oc.fe(v)
+    return x
+
+
+# ---- NTT (ntt.rs:25-71) ------------------------------------------------------
+@pytest.mark.parametrize("log_n", list(range(0, 19)) + [20])
+def test_ntt_forward_inverse_vs_oracle(ctx, log_n):
+    n = 1 << log_n
+    x = _edge_vector(n, 1000 + log_n)
+    f = ctx.ntt(x)
+    assert np.array_equal(f, oc.ntt(x)), f"forward 2^{log_n}"
+    i = ctx.ntt(x, inverse=True)
+    assert np.array_equal(i, oc.ntt(x, inverse=True)), f"inverse 2^{log_n}"
+    assert np.array_equal(ctx.ntt(f, inverse=True), x)
+
+
+@pytest.mark.parametrize("n", [8, 64, 1024])
+def test_ntt_golden(ctx, golden, n):
+    g = golden["ntt"][str(n)]
+    x = oc.splitmix(n, g["seed"])
+    assert ctx.ntt(x).tobytes().hex() == g["forward"]
+    assert ctx.ntt(x, inverse=True).tobytes().hex() == g["inverse"]
+
+
+def test_ntt_4096_u64_inputs_golden(ctx, golden):
+    g = golden["ntt"]["4096_u64"]
+    x = oc.splitmix(4096, g["seed"])
+    x[:, 1] = 0
+    assert hashlib.sha256(ctx.ntt(x).tobytes()).hexdigest() == g["forward_sha256"]
+
+
+def test_ntt_2_22_config(ctx):
+    """BASELINE config: single 2^22-point forward + inverse, bit-exact."""
+    n = 1 << 22
+    x = oc.splitmix(n, 22)
+    f = ctx.ntt(x)
+    assert np.array_equal(f, oc.ntt(x))
+    assert np.array_equal(ctx.ntt(f, inverse=True), x)
+
+
+def test_ntt_2_24_full_size(ctx):
+    n = 1 << 24
+    x = oc.splitmix(n, 24)
+    f = ctx.ntt(x)
+    ref = oc.ntt(x)
+    assert np.array_equal(f, ref)
+    del ref
+    assert np.array_equal(ctx.ntt(f, inverse=True), x)
+
+
+def test_ntt_batch(ctx):
+    for log_n, cols in ((5, 7), (13, 5), (16, 3)):
+        n = 1 << log_n
+        x = oc.splitmix(n * cols, 77 + log_n).reshape(cols, n, 2)
+        out = ctx.ntt_batch(x)
+        for c in range(cols):
+            assert np.array_equal(out[c], oc.ntt(x[c]))
+        back = ctx.ntt_batch(out, inverse=True)
+        assert np.array_equal(back, x)
+
+
+def test_ntt_errors(ctx):
+    from stark_amd import StarkError
+    with pytest.raises(StarkError, match="power of 2"):
+        ctx.ntt(oc.splitmix(12, 1))
+    with pytest.raises(StarkError) as e:
+        ctx.ntt_dev(0, 1 << 31)
+    assert e.value.code in (2, 7)
+
+
+def test_ntt_reference_unit_cases(ctx):
+    """ntt.rs:143-206 through the device: evaluate/interpolate round trips and
+    (1+x)(1+2x) via pointwise product."""
+    x = oc.from_ints([1, 2, 3, 4])
+    assert np.array_equal(ctx.ntt(ctx.ntt(x), inverse=True), x)
+    a = oc.from_ints([1, 1, 0, 0, 0, 0, 0, 0])
+    b = oc.from_ints([1, 2, 0, 0, 0, 0, 0, 0])
+    prod = ctx.ntt(ctx.vec_mul(ctx.ntt(a), ctx.ntt(b)), inverse=True)
+    assert oc.to_ints(prod)[:3] == [1, 3, 2] and not prod[3:].any()
+
+
+def test_vec_mul(ctx):
+    a, b = _edge_vector(5000, 3), _edge_vector(5000, 4)
+    ref = np.empty_like(a)
+    oc.lib.so_fe_mul_vec(oc.p64(a), oc.p64(b), oc.p64(ref), 5000)
+    assert np.array_equal(ctx.vec_mul(a, b), ref)
+
+
+# ---- coset LDE (univariate_poly.rs:44-54 on offset*omega^i) ---------------------
+@pytest.mark.parametrize("n_coeffs,n_out", [(1, 8), (16, 64), (100, 512), (1024, 4096), (2048, 8192),
+                                            (5000, 1 << 15), (1 << 14, 1 << 16), (1 << 18, 1 << 20), (300, 1 << 13)])
+def test_coset_lde_vs_oracle(ctx, n_coeffs, n_out):
+    c = _edge_vector(n_coeffs, n_coeffs + n_out)
+    for off in (G, 1, so.fe_pow(G, 12345)):
+        out = ctx.coset_lde_batch(c, n_out, off)[0]
+        assert np.array_equal(out, oc.coset_lde(c, n_out, off)), (n_coeffs, n_out, off)
+
+
+def test_coset_lde_matches_horner_and_golden(ctx, golden):
+    g = golden["coset_lde"]
+    c = oc.splitmix(g["n_coeffs"], g["seed"])
+    out = ctx.coset_lde_batch(c, g["n_out"], int(g["offset"]))[0]
+    assert out.tobytes().hex() == g["out"]
+    h = np.empty_like(out)
+    oc.lib.so_coset_lde_horner(oc.p64(c), len(c), g["n_out"], oc.p64(oc.fe(G)), oc.p64(h))
+    assert np.array_equal(out, h)
+
+
+def test_coset_lde_batch_columns(ctx):
+    cols, n_coeffs, n_out = 6, 1 << 12, 1 << 14
+    c = oc.splitmix(cols * n_coeffs, 5).reshape(cols, n_coeffs, 2)
+    out = ctx.coset_lde_batch(c, n_out, G)
+    for k in range(cols):
+        assert np.array_equal(out[k], oc.coset_lde(c[k], n_out, G))
+
+
+def test_coset_lde_full_size_column(ctx):
+    """BASELINE config 3 shape, one column: 2^20 coefficients -> 2^22 points."""
+    c = oc.splitmix(1 << 20, 20)
+    out = ctx.coset_lde_batch(c, 1 << 22, G)[0]
+    assert np.array_equal(out, oc.coset_lde(c, 1 << 22, G))
+
+
+# ---- Merkle (merkle.rs) ----------------------------------------------------------
+@pytest.mark.parametrize("log_n", [0, 1, 2, 3, 5, 10, 11, 12, 13, 16])
+def test_merkle_commit_fe_vs_oracle(ctx, log_n):
+    n = 1 << log_n
+    x = _edge_vector(n, 500 + log_n)
+    root, tree = ctx.merkle_commit_fe(x, keep_tree=True)
+    ref_tree = oc.merkle_tree_fe(x)
+    assert root == ref_tree[-1].tobytes() == oc.merkle_commit_fe(x)
+    assert np.array_equal(tree.download(), ref_tree)
+    if n > 1:
+        for idx in {0, 1, n // 2, n - 1}:
+            assert tree.open(idx) == oc.merkle_open(ref_tree, idx)
+    tree.free()
+    assert ctx.merkle_commit_fe(x) == root
+
+
+def test_merkle_leaf_encodings(ctx, golden):
+    """All five bincode lengths (0,1,2,3,4 digits) hash like the restatement."""
+    vals = [int(v) for v, _ in golden["leaf_bytes"]]
+    vals += [0] * (16 - len(vals))
+    x = oc.from_ints(vals)
+    _, tree = ctx.merkle_commit_fe(x, keep_tree=True)
+    lv = tree.download()
+    for i, v in enumerate(vals):
+        assert lv[i].tobytes() == hashlib.blake2b(so.bincode_field_element(v), digest_size=32).digest()
+
+
+def test_merkle_golden(ctx, golden):
+    for n, g in golden["merkle_fe"].items():
+        elems = np.frombuffer(bytes.fromhex(g["elems"]), dtype=np.uint64).reshape(-1, 2).copy()
+        root, tree = ctx.merkle_commit_fe(elems, keep_tree=True)
+        assert root.hex() == g["root"]
+        assert [p.hex() for p in tree.open(1)] == g["open_1"]
+    g = golden["merkle_bytes"]
+    leaves = [bytes.fromhex(l) for l in g["leaves"]]
+    root, tree = ctx.merkle_commit_bytes(leaves, keep_tree=True)
+    assert root.hex() == g["root"]
+    assert [p.hex() for p in tree.open(5)] == g["open_5"]
+
+
+def test_merkle_reference_unit_case(ctx):
+    """merkle.rs:157-206 shape: 64 leaves of 1..99 bytes; open + verify + tamper."""
+    n = 64
+    leaves = [hashlib.shake_256(bytes([i])).digest(1 + (i * 7) % 99) for i in range(n)]
+    root, tree = ctx.merkle_commit_bytes(leaves, keep_tree=True)
+    assert root == so.merkle_commit(leaves)
+    for i in range(n):
+        path = tree.open(i)
+        assert so.merkle_verify(root, i, path, leaves[i])
+        assert not so.merkle_verify(root, (i + 1) % n, path, leaves[i])
+    # long leaves (multi-block BLAKE2b) and empty leaves
+    leaves = [b"", b"a" * 128, b"b" * 129, b"c" * 1000]
+    assert ctx.merkle_commit_bytes(leaves) == so.merkle_commit(leaves)
+
+
+def test_merkle_errors(ctx):
+    from stark_amd import StarkError
+    with pytest.raises(StarkError, match="power of two"):
+        ctx.merkle_commit_fe(oc.splitmix(3, 1))
+    _, tree = ctx.merkle_commit_fe(oc.splitmix(8, 1), keep_tree=True)
+    with pytest.raises(StarkError, match="invalid index"):
+        tree.open(8)
+
+
+def test_merkle_full_size_root(ctx):
+    n = 1 << 22
+    x = oc.splitmix(n, 9)
+    assert ctx.merkle_commit_fe(x) == oc.merkle_commit_fe(x)
+
+
+# ---- FRI (fri.rs) -------------------------------------------------------------------
+@pytest.mark.parametrize("log_n", [1, 2, 8, 9, 13, 18])
+def test_fri_fold_vs_oracle(ctx, log_n):
+    n = 1 << log_n
+    cw = _edge_vector(n, 40 + log_n)
+    alpha = so.fe_sample(hashlib.sha256(bytes([log_n])).digest())
+    omega = so.primitive_nth_root(n)
+    for off in (G, 1):
+        assert np.array_equal(ctx.fri_fold(cw, alpha, off, omega), oc.fri_fold(cw, alpha, off, omega))
+    # a non-standard root of the right order (omega^3 is also primitive)
+    if n >= 8:
+        w3 = so.fe_pow(omega, 3)
+        assert np.array_equal(ctx.fri_fold(cw, alpha, G, w3), oc.fri_fold(cw, alpha, G, w3))
+
+
+def test_fri_fold_literal_reference_form(ctx):
+    n = 64
+    cw = oc.splitmix(n, 2)
+    alpha = 123456789
+    omega = so.primitive_nth_root(n)
+    lit = so.fri_fold(oc.to_ints(cw), alpha, G, omega)
+    assert oc.to_ints(ctx.fri_fold(cw, alpha, G, omega)) == lit
+
+
+def _commit_with_python_transcript(ctx, cw, offset, omega, expansion, ncol):
+    ps = so.ProofStream()
+    alphas = []
+
+    def transcript(rnd, last, root):
+        ps.push(root.hex())                                   # fri.rs:120
+        if last:
+            return None
+        a = so.fe_sample(ps.prover_fiat_shamir(32))           # fri.rs:126-127
+        alphas.append(a)
+        return a
+
+    layers = ctx.fri_commit(cw, offset, omega, expansion, ncol, transcript)
+    last = layers.download(len(layers) - 1)
+    ps.push(so.json_field_vec(oc.to_ints(last)))              # fri.rs:146
+    return layers, ps, alphas
+
+
+@pytest.mark.parametrize("log_n,expansion,ncol", [(8, 4, 17), (6, 4, 2), (10, 8, 8), (12, 4, 17), (16, 4, 17), (20, 4, 17)])
+def test_fri_commit_vs_oracle(ctx, log_n, expansion, ncol):
+    n = 1 << log_n
+    coeffs = oc.splitmix(n // expansion, 900 + log_n)
+    cw = oc.coset_lde(coeffs, n, G)
+    omega = so.primitive_nth_root(n)
+    layers, ps, alphas = _commit_with_python_transcript(ctx, cw, G, omega, expansion, ncol)
+    ref_layers, ref_roots, ref_alphas, ref_stream = oc.fri_commit(cw, G, omega, expansion, ncol)
+    assert len(layers) == len(ref_layers) == ctx.fri_num_rounds(n, expansion, ncol)
+    assert [layers.root(i) for i in range(len(layers))] == ref_roots
+    assert alphas == ref_alphas
+    for i in range(len(layers)):
+        assert np.array_equal(layers.download(i), ref_layers[i]), f"layer {i}"
+    assert ps.objects == ref_stream.objects
+    # openings from the retained trees (fri.rs:187-201) and point reads (fri.rs:166-179)
+    for i in (0, len(layers) - 1):
+        m = layers.layer_len(i)
+        ref_tree = oc.merkle_tree_fe(ref_layers[i])
+        for idx in (0, m // 2 + 1, m - 1):
+            assert layers.open(i, idx) == oc.merkle_open(ref_tree, idx)
+        idxs = [0, m - 1, m // 3]
+        assert np.array_equal(layers.read(i, idxs), ref_layers[i][idxs])
+
+
+def test_fri_commit_reference_test_params_golden(ctx, golden):
+    g = golden["fri_commit_ref_test"]
+    cw = np.frombuffer(bytes.fromhex(g["codeword"]), dtype=np.uint64).reshape(-1, 2).copy()
+    omega = so.primitive_nth_root(g["n0"])
+    layers, ps, _ = _commit_with_python_transcript(ctx, cw, G, omega, g["expansion"], g["ncol"])
+    assert ps.objects == g["objects"]
+    assert layers.download(len(layers) - 1).tobytes().hex() == g["last_codeword"]
+
+
+def test_fri_commit_errors(ctx):
+    from stark_amd import StarkError
+    cw = oc.splitmix(64, 1)
+    with pytest.raises(StarkError, match="less than 1 round"):
+        ctx.fri_commit(cw[:4].copy(), G, so.primitive_nth_root(4), 4, 1, lambda *a: 1)
+    with pytest.raises(StarkError, match="right order"):
+        ctx.fri_commit(cw, G, so.primitive_nth_root(128), 4, 2, lambda *a: 1)
+
+    def boom(*a):
+        raise KeyError("transcript")
+    with pytest.raises(KeyError):
+        ctx.fri_commit(cw, G, so.primitive_nth_root(64), 4, 2, boom)
+
+
+def test_fri_commit_2_24_full_size(ctx):
+    """BASELINE config 4: 2^24 codeword, blowup 4, 17 colinearity tests: 18
+    roots, 17 folds.  Checked against the C restatement root by root."""
+    n = 1 << 24
+    coeffs = oc.splitmix(n // 4, 2424)
+    cw = oc.coset_lde(coeffs, n, G)
+    omega = so.primitive_nth_root(n)
+    layers, ps, alphas = _commit_with_python_transcript(ctx, cw, G, omega, 4, 17)
+    assert len(layers) == 18
+    ref_layers, ref_roots, ref_alphas, ref_stream = oc.fri_commit(cw, G, omega, 4, 17)
+    assert [layers.root(i) for i in range(18)] == ref_roots
+    assert alphas == ref_alphas
+    assert ps.objects == ref_stream.objects
+    assert np.array_equal(layers.download(17), ref_layers[17])
+    assert np.array_equal(layers.download(5), ref_layers[5])
