@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""Benchmark of the STARK prover hot path on MI355X.
+
+Contract: python bench.py --gpus N --steps K --warmup W  ->  ONE JSON line on
+rank 0.  A step is one forward + one inverse 2^22-point NTT over the 128-bit
+field (BASELINE.json configs[1]) on device-resident data; with N > 1 every rank
+transforms its own vector (independent units, no collective: weak scaling) and
+`value` is the whole-job rate.  The same line carries the roofline of the
+dominant kernel family and the CPU restatement timed on the host cores, plus
+the other headline numbers (2^24 NTT, 2^24 FRI commit, batched coset LDE) under
+"extra".
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+LOG_N = 22
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak
+
+
+def _events_ms(torch, fn, reps):
+    """Average milliseconds of fn() over reps, HIP events on the current stream."""
+    start = torch.cuda.Event(enable_timing=True)
+    stop = torch.cuda.Event(enable_timing=True)
+    start.record()
+    for _ in range(reps):
+        fn()
+    stop.record()
+    stop.synchronize()
+    return start.elapsed_time(stop) / reps
+
+
+def cpu_baseline(log_n: int, reps: int):
+    """The C restatement (oracle/stark_oracle.c, one thread) on the same
+    workload: forward + inverse NTT of 2^log_n elements."""
+    import oracle_c as oc
+    n = 1 << log_n
+    x = oc.splitmix(n, 0x5741524B)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        y = oc.ntt(x)
+        oc.ntt(y, inverse=True)
+    dt = time.perf_counter() - t0
+    return {
+        "value": round(2 * n * reps / dt / 1e6, 4), "unit": "Melem/s", "cores": 1, "kind": "port",
+        "sample": f"{reps} x (forward+inverse) NTT at 2^{log_n}, single thread, C restatement of ntt.rs",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-extra", action="store_true", help="skip the 2^24 / FRI / LDE side measurements")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+
+    from stark_amd import Context, GENERATOR
+    import oracle_c as oc                       # synthetic data generator + cpu_baseline leg only
+    import stark_oracle as so
+
+    ctx = Context(dev.index)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    n = 1 << LOG_N
+    host = oc.splitmix(n, 0x5741524B + rank)
+    data = torch.from_numpy(host.view(np.int64)).to(dev)
+    orig = data.clone()
+
+    def step():
+        ctx.ntt_dev(data, n, inverse=False)
+        ctx.ntt_dev(data, n, inverse=True)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ev_start = torch.cuda.Event(enable_timing=True)
+    ev_stop = torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev_start.record()
+    for _ in range(args.steps):
+        step()
+    ev_stop.record()
+    barrier()
+    dt = time.perf_counter() - t0
+    kernel_ms_total = ev_start.elapsed_time(ev_stop)
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    # the transform pair must give the input back, bit for bit
+    assert torch.equal(data, orig), "forward+inverse NTT did not round-trip"
+
+    result = None
+    if rank == 0:
+        passes_per_ntt = 3                                     # 2^22 = 2^8 * 2^7 * 2^7
+        launches = args.steps * 2 * passes_per_ntt
+        avg_launch_ms = kernel_ms_total / launches
+        alg_bytes = 32.0 * n                                   # each pass reads and writes every element once
+        achieved = alg_bytes / (avg_launch_ms * 1e-3) / 1e9
+        result = {
+            "metric": "128-bit-field NTT throughput, 2^22-point forward+inverse",
+            "value": round(world * 2 * n * args.steps / dt / 1e6, 2),
+            "unit": "Melem/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u128 (mod 407*2^119+1)", "data": "synthetic",
+            "config": {"workload": "single 2^22-point forward+inverse NTT per GPU, data resident in HBM",
+                       "log_n": LOG_N, "elements_per_step": 2 * n, "parallelism": f"independent x{world}"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel": "ntt_pass_kernel (3 launches per transform)",
+                         "avg_launch_us": round(avg_launch_ms * 1e3, 2)},
+        }
+
+    extra = {}
+    if not args.no_extra and rank == 0:
+        # forward-only and inverse-only at 2^22
+        extra["ntt_2^22_fwd_ms"] = round(_events_ms(torch, lambda: ctx.ntt_dev(data, n, False), 20), 4)
+        extra["ntt_2^22_inv_ms"] = round(_events_ms(torch, lambda: ctx.ntt_dev(data, n, True), 20), 4)
+        extra["ntt_2^22_fwd_Melem_s"] = round(n / extra["ntt_2^22_fwd_ms"] / 1e3, 1)
+        # 2^24 forward / inverse
+        n24 = 1 << 24
+        d24 = torch.from_numpy(oc.splitmix(n24, 24).view(np.int64)).to(dev)
+        for _ in range(3):
+            ctx.ntt_dev(d24, n24, False)
+        extra["ntt_2^24_fwd_ms"] = round(_events_ms(torch, lambda: ctx.ntt_dev(d24, n24, False), 10), 4)
+        extra["ntt_2^24_inv_ms"] = round(_events_ms(torch, lambda: ctx.ntt_dev(d24, n24, True), 10), 4)
+        extra["ntt_2^24_fwd_Melem_s"] = round(n24 / extra["ntt_2^24_fwd_ms"] / 1e3, 1)
+        # Merkle commitment of 2^24 leaves
+        ctx.merkle_commit_fe_dev(d24, n24)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            ctx.merkle_commit_fe_dev(d24, n24)
+        torch.cuda.synchronize()
+        extra["merkle_2^24_ms"] = round((time.perf_counter() - t0) / 3 * 1e3, 3)
+        extra["merkle_2^24_Mhash_s"] = round((2 * n24 - 1) / extra["merkle_2^24_ms"] / 1e3, 1)
+        # FRI commit on a 2^24 codeword (blowup 4, 17 colinearity tests: 18 roots, 17 folds)
+        omega = so.primitive_nth_root(n24)
+
+        def fri_once():
+            ps = so.ProofStream()
+
+            def transcript(rnd, last, root):
+                ps.push(root.hex())
+                return None if last else so.fe_sample(ps.prover_fiat_shamir(32))
+            layers = ctx.fri_commit(d24, GENERATOR, omega, 4, 17, transcript, n=n24)
+            layers.free()
+
+        fri_once()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            fri_once()
+        torch.cuda.synchronize()
+        extra["fri_commit_2^24_ms"] = round((time.perf_counter() - t0) / 3 * 1e3, 3)
+        del d24
+        # batched coset LDE: 16 of the 64 columns of config 3 (2^20 coefficients -> 2^22 points each)
+        cols = 16
+        coeffs = torch.from_numpy(oc.splitmix(cols << 20, 3).view(np.int64)).to(dev)
+        out = torch.empty((cols << 22, 2), dtype=torch.int64, device=dev)
+        lde = lambda: ctx.coset_lde_batch_dev(coeffs, 1 << 20, 1 << 20, cols, 1 << 22, GENERATOR, out, 1 << 22)  # noqa: E731
+        lde()
+        extra["coset_lde_16x2^20_to_2^22_ms"] = round(_events_ms(torch, lde, 5), 3)
+        extra["coset_lde_Melem_s_out"] = round((cols << 22) / extra["coset_lde_16x2^20_to_2^22_ms"] / 1e3, 1)
+        del coeffs, out
+
+    if rank == 0:
+        if not args.no_cpu:
+            result["cpu_baseline"] = cpu_baseline(LOG_N, 2)
+        else:
+            result["cpu_baseline"] = None
+        result["extra"] = extra
+        print(json.dumps(result), flush=True)
+
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

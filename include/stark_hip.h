@@ -4,7 +4,7 @@
  * BLAKE2b Merkle commitment over p = 407 * 2^119 + 1.
  *
  * These are the entry points an FFI binding of the reference crate
- * (`zk_stark`, src/modules/*.rs) binds; each one names the reference function
+ * (`zk_stark`, the files under src/modules) binds; each one names the reference function
  * it stands in for.  Conventions:
  *   - a field element is 16 bytes: two little-endian uint64_t {lo, hi}, a
  *     canonical integer in [0, p) (the packed image of FieldElement.value,
@@ -51,8 +51,11 @@ enum {
 /* ---- context ------------------------------------------------------------ */
 int32_t stark_ctx_create(int32_t device, stark_ctx** out);
 void stark_ctx_destroy(stark_ctx* ctx);
-/* Run on an existing hipStream_t (e.g. the caller's current stream); NULL = the context's own stream. */
+/* A new context launches on a stream of its own.  stark_ctx_set_stream makes it
+ * launch on the caller's hipStream_t instead (NULL = HIP's default stream);
+ * stark_ctx_reset_stream goes back to the context's own stream. */
 int32_t stark_ctx_set_stream(stark_ctx* ctx, void* hip_stream);
+int32_t stark_ctx_reset_stream(stark_ctx* ctx);
 int32_t stark_ctx_synchronize(stark_ctx* ctx);
 const char* stark_last_error(void);
 

@@ -24,6 +24,7 @@ SIGNATURES = {
     "stark_ctx_create": (i32, [i32, voidpp]),
     "stark_ctx_destroy": (None, [C.c_void_p]),
     "stark_ctx_set_stream": (i32, [C.c_void_p, C.c_void_p]),
+    "stark_ctx_reset_stream": (i32, [C.c_void_p]),
     "stark_ctx_synchronize": (i32, [C.c_void_p]),
     "stark_dev_alloc": (i32, [C.c_void_p, sz, voidpp]),
     "stark_dev_free": (i32, [C.c_void_p, C.c_void_p]),

@@ -47,21 +47,24 @@ namespace {
 struct NttTables {
     uint32_t log_n = 0, h = 0;
     std::vector<uint32_t> radices;   // empty for the single-workgroup path
-    fe* tw16 = nullptr;
-    fe* tw256 = nullptr;
-    fe* hi = nullptr;
-    fe* lo = nullptr;
-    fe* small = nullptr;             // omega_n^i, i < n/2 (n <= 4096)
-    fe scale_m{0, 0};                // n^-1, Montgomery form
+    tw5* tw16 = nullptr;             // multi-pass path: five-limb Montgomery forms (2^156)
+    tw5* tw256 = nullptr;
+    tw5* hi = nullptr;
+    tw5* lo = nullptr;
+    tw5* fin = nullptr;              // 1, or n^-1 for the inverse
+    fe* small = nullptr;             // omega_n^i, i < n/2 (n <= 4096), Montgomery form (2^128)
+    fe scale_m{0, 0};                // n^-1, Montgomery form (2^128)
 };
 
-struct PowTables {                   // powers of one element x: lo[i] = x^i (i<256), hi[i] = x^(256 i)
-    fe* hi = nullptr;
-    fe* lo = nullptr;
+// powers of one element x: lo[i] = x^i (i<256), hi[i] = x^(256 i); either as
+// 16-byte Montgomery forms (2^128) or as five-limb forms (2^156)
+struct PowTables {
+    void* hi = nullptr;
+    void* lo = nullptr;
     size_t hi_len = 0;
 };
 
-typedef std::tuple<uint64_t, uint64_t, uint64_t> PowKey;   // (x.lo, x.hi, hi_len)
+typedef std::tuple<uint64_t, uint64_t, uint64_t, int> PowKey;   // (x.lo, x.hi, hi_len, five-limb?)
 
 }  // namespace
 
@@ -138,10 +141,11 @@ static void pool_free(stark_ctx* ctx, void* p, size_t bytes)
     ctx->pool.emplace(bytes, p);
 }
 
-static int32_t upload(stark_ctx* ctx, const std::vector<fe>& v, fe** out)
+template <class T>
+static int32_t upload(stark_ctx* ctx, const std::vector<T>& v, T** out)
 {
-    HIP_TRY(hipMalloc((void**)out, v.size() * sizeof(fe)));
-    HIP_TRY(hipMemcpy(*out, v.data(), v.size() * sizeof(fe), hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc((void**)out, v.size() * sizeof(T)));
+    HIP_TRY(hipMemcpy(*out, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
     (void)ctx;
     return STARK_OK;
 }
@@ -155,6 +159,33 @@ static std::vector<fe> powers_m(const HostField& F, fe x, size_t count)
     for (size_t i = 0; i < count; i++) {
         v[i] = cur;
         cur = mont_mul(cur, xm);
+    }
+    return v;
+}
+
+// canonical value -> five-limb Montgomery form (x * 2^156 mod p)
+static tw5 to_tw5(const HostField& F, fe x)
+{
+    static const fe r156 = [] {
+        fe r{1, 0};
+        for (int i = 0; i < 156; i++) r = fe_add(r, r);
+        return r;
+    }();
+    fe5 l = unpack5(F.mul(x, r156));
+    tw5 t{};
+    for (int i = 0; i < 5; i++) t.l[i] = l.l[i];
+    return t;
+}
+
+// powers x^0, x^1, ... as five-limb Montgomery forms
+static std::vector<tw5> powers_5(const HostField& F, fe x, size_t count)
+{
+    std::vector<tw5> v(count);
+    fe xm = F.to_mont(x);
+    fe cur = fe{1, 0};
+    for (size_t i = 0; i < count; i++) {
+        v[i] = to_tw5(F, cur);
+        cur = mont_mul(cur, xm);       // canonical * Montgomery form -> canonical
     }
     return v;
 }
@@ -192,25 +223,24 @@ static int32_t get_ntt_tables(stark_ctx* ctx, uint32_t log_n, bool inverse, cons
         t.h = t.radices.back();
         fe w16 = F.pow(omega, (u128)1 << (log_n - 4));
         fe w256 = F.pow(omega, (u128)1 << (log_n - 8));
-        ST_TRY(upload(ctx, powers_m(F, w16, 8), &t.tw16));
-        ST_TRY(upload(ctx, powers_m(F, w256, 256), &t.tw256));
+        ST_TRY(upload(ctx, powers_5(F, w16, 8), &t.tw16));
+        ST_TRY(upload(ctx, powers_5(F, w256, 256), &t.tw256));
         fe w_hi = F.pow(omega, (u128)1 << t.h);
-        ST_TRY(upload(ctx, powers_m(F, w_hi, (size_t)1 << (log_n - t.h)), &t.hi));
-        std::vector<fe> lo = powers_m(F, omega, (size_t)1 << t.h);
-        if (inverse)
-            for (auto& x : lo) x = mont_mul(x, t.scale_m);    // fold n^-1 into the last-pass twiddle
-        ST_TRY(upload(ctx, lo, &t.lo));
+        ST_TRY(upload(ctx, powers_5(F, w_hi, (size_t)1 << (log_n - t.h)), &t.hi));
+        ST_TRY(upload(ctx, powers_5(F, omega, (size_t)1 << t.h), &t.lo));
+        std::vector<tw5> fin(1, to_tw5(F, inverse ? n_inv : fe{1, 0}));   // ntt.rs:36-39 folded into the last pass
+        ST_TRY(upload(ctx, fin, &t.fin));
     }
     auto ins = ctx->ntt_tables.emplace(key, t);
     *out = &ins.first->second;
     return STARK_OK;
 }
 
-static int32_t get_pow_tables(stark_ctx* ctx, fe x, size_t count, const PowTables** out)
+static int32_t get_pow_tables(stark_ctx* ctx, fe x, size_t count, bool five, const PowTables** out)
 {
     size_t hi_len = (count + 255) / 256;
     if (hi_len == 0) hi_len = 1;
-    PowKey key(x.lo, x.hi, hi_len);
+    PowKey key(x.lo, x.hi, hi_len, five ? 1 : 0);
     auto it = ctx->pow_tables.find(key);
     if (it != ctx->pow_tables.end()) {
         *out = &it->second;
@@ -226,8 +256,13 @@ static int32_t get_pow_tables(stark_ctx* ctx, fe x, size_t count, const PowTable
     const HostField& F = ctx->F;
     PowTables t;
     t.hi_len = hi_len;
-    ST_TRY(upload(ctx, powers_m(F, x, 256), &t.lo));
-    ST_TRY(upload(ctx, powers_m(F, F.pow(x, 256), hi_len), &t.hi));
+    if (five) {
+        ST_TRY(upload(ctx, powers_5(F, x, 256), (tw5**)&t.lo));
+        ST_TRY(upload(ctx, powers_5(F, F.pow(x, 256), hi_len), (tw5**)&t.hi));
+    } else {
+        ST_TRY(upload(ctx, powers_m(F, x, 256), (fe**)&t.lo));
+        ST_TRY(upload(ctx, powers_m(F, F.pow(x, 256), hi_len), (fe**)&t.hi));
+    }
     auto ins = ctx->pow_tables.emplace(key, t);
     *out = &ins.first->second;
     return STARK_OK;
@@ -251,17 +286,19 @@ static int32_t ensure_scratch(stark_ctx* ctx, size_t elems)
 // (zero padded to n), writes n elements at dst + c*dst_stride.  All device
 // pointers.  twist == nullptr means offset 1.
 static int32_t run_ntt(stark_ctx* ctx, const fe* src, size_t src_stride, size_t n_src, fe* dst,
-                       size_t dst_stride, uint32_t log_n, bool inverse, const PowTables* twist, size_t n_cols)
+                       size_t dst_stride, uint32_t log_n, bool inverse, const fe* twist_x, size_t n_cols)
 {
     if (n_cols == 0) return STARK_OK;
     const NttTables* t;
     ST_TRY(get_ntt_tables(ctx, log_n, inverse, &t));
     const size_t n = (size_t)1 << log_n;
+    const PowTables* twist = nullptr;
+    if (twist_x) ST_TRY(get_pow_tables(ctx, *twist_x, n_src, log_n > (uint32_t)SMALL_MAX_LOG, &twist));
     if (log_n <= (uint32_t)SMALL_MAX_LOG) {
         SmallArgs a{};
         a.tw = t->small;
-        a.twist_hi = twist ? twist->hi : nullptr;
-        a.twist_lo = twist ? twist->lo : nullptr;
+        a.twist_hi = twist ? (const fe*)twist->hi : nullptr;
+        a.twist_lo = twist ? (const fe*)twist->lo : nullptr;
         a.scale_m = t->scale_m;
         a.src_batch_stride = src_stride;
         a.dst_batch_stride = dst_stride;
@@ -294,8 +331,11 @@ static int32_t run_ntt(stark_ctx* ctx, const fe* src, size_t src_stride, size_t 
             a.tw256 = t->tw256;
             a.hi = t->hi;
             a.lo = t->lo;
+            a.fin = t->fin;
             a.log_n = log_n;
             a.log_s = log_s;
+            a.log_s_next = (q + 1 < P) ? log_s - t->radices[q + 1] : 0;
+            a.next_is_last = (q + 2 == P) ? 1 : 0;
             a.r = t->radices[q];
             a.h = t->h;
             a.nprev = (uint32_t)q;
@@ -307,8 +347,8 @@ static int32_t run_ntt(stark_ctx* ctx, const fe* src, size_t src_stride, size_t 
                 a.src = src + c0 * src_stride;
                 a.src_batch_stride = src_stride;
                 a.n_src = n_src;
-                a.twist_hi = twist ? twist->hi : nullptr;
-                a.twist_lo = twist ? twist->lo : nullptr;
+                a.twist_hi = twist ? (const tw5*)twist->hi : nullptr;
+                a.twist_lo = twist ? (const tw5*)twist->lo : nullptr;
             } else {
                 mode = (q == P - 1) ? PASS_LAST : PASS_MIDDLE;
                 a.src = ctx->scratch;
@@ -420,7 +460,8 @@ extern "C" void stark_ctx_destroy(stark_ctx* ctx)
     (void)hipStreamSynchronize(ctx->stream);
     for (auto& kv : ctx->ntt_tables) {
         NttTables& t = kv.second;
-        (void)hipFree(t.tw16); (void)hipFree(t.tw256); (void)hipFree(t.hi); (void)hipFree(t.lo); (void)hipFree(t.small);
+        (void)hipFree(t.tw16); (void)hipFree(t.tw256); (void)hipFree(t.hi); (void)hipFree(t.lo); (void)hipFree(t.fin);
+        (void)hipFree(t.small);
     }
     for (auto& kv : ctx->pow_tables) { (void)hipFree(kv.second.hi); (void)hipFree(kv.second.lo); }
     for (auto& kv : ctx->pool) (void)hipFree(kv.second);
@@ -434,7 +475,15 @@ extern "C" int32_t stark_ctx_set_stream(stark_ctx* ctx, void* hip_stream)
 {
     if (!ctx) return fail(STARK_EARG, "null context");
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    ctx->stream = (hipStream_t)hip_stream;
+    return STARK_OK;
+}
+
+extern "C" int32_t stark_ctx_reset_stream(stark_ctx* ctx)
+{
+    if (!ctx) return fail(STARK_EARG, "null context");
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->stream = ctx->own_stream;
     return STARK_OK;
 }
 
@@ -539,8 +588,7 @@ extern "C" int32_t stark_coset_lde_batch_dev(stark_ctx* ctx, const uint64_t* coe
         return fail(STARK_ELENGTH, "stride smaller than column length");
     fe off{offset[0], offset[1]};
     if (!is_canonical(off)) return fail(STARK_EARG, "offset not reduced modulo p");
-    const PowTables* twist = nullptr;
-    if (!is_one(off) && n_coeffs > 0) ST_TRY(get_pow_tables(ctx, off, n_coeffs, &twist));
+    const fe* twist = (!is_one(off) && n_coeffs > 0) ? &off : nullptr;
     return run_ntt(ctx, (const fe*)coeffs_dev, coeff_stride, n_coeffs, (fe*)out_dev, out_stride, (uint32_t)log_n,
                    false, twist, n_cols);
 }
@@ -693,7 +741,7 @@ extern "C" size_t stark_fri_num_rounds(size_t domain_length, size_t expansion_fa
 // power tables of omega^-1 covering exponents < N
 static int32_t fold_tables(stark_ctx* ctx, fe omega, size_t N, const PowTables** out)
 {
-    return get_pow_tables(ctx, ctx->F.inverse(omega), N, out);
+    return get_pow_tables(ctx, ctx->F.inverse(omega), N, false, out);
 }
 
 static fe fold_constant(const HostField& F, fe alpha, fe offset)
@@ -716,8 +764,8 @@ extern "C" int32_t stark_fri_fold_dev(stark_ctx* ctx, const uint64_t* codeword_d
     a.cw = (const fe*)codeword_dev;
     a.out = (fe*)out_dev;
     a.leaf_out = nullptr;
-    a.hi = pt->hi;
-    a.lo = pt->lo;
+    a.hi = (const fe*)pt->hi;
+    a.lo = (const fe*)pt->lo;
     a.c_m = fold_constant(ctx->F, al, of);
     a.half = N / 2;
     a.shift = 0;
@@ -824,8 +872,8 @@ static int32_t fri_commit_impl(stark_ctx* ctx, const fe* cw_src, bool src_is_hos
         a.cw = L->cw[r];
         a.out = L->cw[r + 1];
         a.leaf_out = L->tree[r + 1];
-        a.hi = pt->hi;
-        a.lo = pt->lo;
+        a.hi = (const fe*)pt->hi;
+        a.lo = (const fe*)pt->lo;
         a.c_m = fold_constant(F, alpha, offset_r);
         a.half = n / 2;
         a.shift = (uint32_t)r;

@@ -1,0 +1,207 @@
+// Lazy 5-limb arithmetic for the butterfly kernels.
+//
+// gfx950 has no fast carry chain: a VALU instruction that consumes VCC needs
+// wait states after the one that produced it, so 128-bit modular add/sub on
+// 32-bit limbs costs ~75 cycles per wave and the 4-limb Montgomery product
+// ~400.  Here an element is five SIGNED 32-bit limbs in base 2^26,
+//     value = l0 + l1*2^26 + l2*2^52 + l3*2^78 + l4*2^104,
+// add/sub are five independent 32-bit operations with no carries (limbs may
+// grow to 31 bits between multiplications), and the product accumulates
+// columns in 64-bit registers with v_mad_i64_i32, propagating carries by
+// shifts.  p = 1 + P4*2^104 with P4 = 407*2^15, so a Montgomery digit step is
+// m = digit, T -= m*p: the low digit cancels by construction and only one
+// multiply-add (m * P4, four digits up) is needed.
+//
+// mont_mul5(a, w) returns a*w*2^-156 mod p up to a multiple of p, in
+// (-2^107, p + 2^107], for ANY int32 limbs of a and a normalised w (limbs in
+// [0, 2^26), value < p).  Six digit steps (R = 2^156) rather than five make the
+// result nearly canonical whatever the laziness of a.  Twiddles are stored as
+// w*2^156 mod p (struct tw5).  pack_canonical() finishes the reduction.
+#pragma once
+#include <stdint.h>
+
+#include "field.hpp"
+
+namespace starkf {
+
+constexpr int LIMB_BITS = 26;
+constexpr int32_t LIMB_MASK = (1 << LIMB_BITS) - 1;
+constexpr int32_t P4 = 407 << 15;             // p = 1 + P4 * 2^104
+
+struct fe5 {
+    int32_t l[5];
+};
+
+// a twiddle: five normalised limbs of (w * 2^156 mod p), padded to 32 bytes
+struct alignas(32) tw5 {
+    int32_t l[5];
+    int32_t pad[3];
+};
+
+STARK_HD uint32_t alignbit32(uint32_t hi, uint32_t lo, uint32_t s)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbit(hi, lo, s);
+#else
+    return (uint32_t)((((uint64_t)hi << 32) | lo) >> s);
+#endif
+}
+
+// canonical 128-bit value -> normalised limbs
+STARK_HD fe5 unpack5(fe a)
+{
+    const uint32_t w0 = (uint32_t)a.lo, w1 = (uint32_t)(a.lo >> 32), w2 = (uint32_t)a.hi, w3 = (uint32_t)(a.hi >> 32);
+    fe5 r;
+    r.l[0] = (int32_t)(w0 & LIMB_MASK);
+    r.l[1] = (int32_t)(alignbit32(w1, w0, 26) & LIMB_MASK);
+    r.l[2] = (int32_t)(alignbit32(w2, w1, 20) & LIMB_MASK);
+    r.l[3] = (int32_t)(alignbit32(w3, w2, 14) & LIMB_MASK);
+    r.l[4] = (int32_t)(w3 >> 8);
+    return r;
+}
+
+STARK_HD fe5 add5(const fe5& a, const fe5& b)
+{
+    fe5 r;
+#pragma unroll
+    for (int i = 0; i < 5; i++) r.l[i] = a.l[i] + b.l[i];
+    return r;
+}
+
+STARK_HD fe5 sub5(const fe5& a, const fe5& b)
+{
+    fe5 r;
+#pragma unroll
+    for (int i = 0; i < 5; i++) r.l[i] = a.l[i] - b.l[i];
+    return r;
+}
+
+// a * w * 2^-156 (mod p), result limbs: l0 in [1, 2^26], l1..l3 in [0, 2^26),
+// l4 = small signed carry + P4; value in (-2^107, p + 2^107].
+STARK_HD int64_t mad64(int32_t a, int32_t b, int64_t c) { return (int64_t)a * (int64_t)b + c; }
+
+template <class W>
+STARK_HD fe5 mont_mul5(const fe5& a, const W& w)
+{
+    const int32_t a0 = a.l[0], a1 = a.l[1], a2 = a.l[2], a3 = a.l[3], a4 = a.l[4];
+    const int32_t w0 = w.l[0], w1 = w.l[1], w2 = w.l[2], w3 = w.l[3], w4 = w.l[4];
+    const int32_t NP4 = -P4;
+    int64_t t;
+    int32_t m0, m1, m2, m3, m4, m5;
+    // each column is one chain of multiply-adds that starts from the carry of
+    // the column below
+    t = mad64(a0, w0, 0);
+    m0 = (int32_t)t & LIMB_MASK;
+    t >>= LIMB_BITS;
+    t = mad64(a0, w1, t);
+    t = mad64(a1, w0, t);
+    m1 = (int32_t)t & LIMB_MASK;
+    t >>= LIMB_BITS;
+    t = mad64(a0, w2, t);
+    t = mad64(a1, w1, t);
+    t = mad64(a2, w0, t);
+    m2 = (int32_t)t & LIMB_MASK;
+    t >>= LIMB_BITS;
+    t = mad64(a0, w3, t);
+    t = mad64(a1, w2, t);
+    t = mad64(a2, w1, t);
+    t = mad64(a3, w0, t);
+    m3 = (int32_t)t & LIMB_MASK;
+    t >>= LIMB_BITS;
+    t = mad64(a0, w4, t);
+    t = mad64(a1, w3, t);
+    t = mad64(a2, w2, t);
+    t = mad64(a3, w1, t);
+    t = mad64(a4, w0, t);
+    t = mad64(m0, NP4, t);
+    m4 = (int32_t)t & LIMB_MASK;
+    t >>= LIMB_BITS;
+    t = mad64(a1, w4, t);
+    t = mad64(a2, w3, t);
+    t = mad64(a3, w2, t);
+    t = mad64(a4, w1, t);
+    t = mad64(m1, NP4, t);
+    m5 = (int32_t)t & LIMB_MASK;
+    t >>= LIMB_BITS;
+    fe5 r;
+    t = mad64(a2, w4, t);
+    t = mad64(a3, w3, t);
+    t = mad64(a4, w2, t);
+    t = mad64(m2, NP4, t);
+    r.l[0] = ((int32_t)t & LIMB_MASK) + 1;            // + p, low digit
+    t >>= LIMB_BITS;
+    t = mad64(a3, w4, t);
+    t = mad64(a4, w3, t);
+    t = mad64(m3, NP4, t);
+    r.l[1] = (int32_t)t & LIMB_MASK;
+    t >>= LIMB_BITS;
+    t = mad64(a4, w4, t);
+    t = mad64(m4, NP4, t);
+    r.l[2] = (int32_t)t & LIMB_MASK;
+    t >>= LIMB_BITS;
+    t = mad64(m5, NP4, t);
+    r.l[3] = (int32_t)t & LIMB_MASK;
+    t >>= LIMB_BITS;
+    r.l[4] = (int32_t)t + P4;                          // + p, high digit
+    return r;
+}
+
+// Exact reduction of any limb vector with |value| < 2^150 into [0, p); the slow
+// path behind pack_canonical.
+STARK_HD fe reduce5_slow(const fe5& r)
+{
+    // carry-propagate into normalised digits with a signed top
+    int64_t c = 0;
+    int64_t d[5];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        c += r.l[i];
+        d[i] = c & LIMB_MASK;
+        c >>= LIMB_BITS;
+    }
+    d[4] = c + r.l[4];                                  // signed, |d4| < 2^46
+    // value = L + d4 * 2^104, 0 <= L < 2^104.  Remove q = floor(d4 / P4) copies of p:
+    // p = 1 + P4*2^104, so value - q*p = (L - q) + (d4 - q*P4) * 2^104.
+    int64_t q = d[4] / P4;
+    if (d[4] % P4 < 0) q -= 1;
+    int64_t top = d[4] - q * P4;                        // in [0, P4)
+    // low part L - q with |q| < 2^23, fixed up against top so that the value
+    // top*2^104 + low lands in [0, p).  (p itself does not fit a signed 128-bit
+    // integer, so the two parts are handled separately.)
+    const __int128 B104 = (__int128)1 << 104;
+    __int128 low = (__int128)d[0] + ((__int128)d[1] << 26) + ((__int128)d[2] << 52) + ((__int128)d[3] << 78) - q;
+    if (low < 0) {
+        if (top > 0) { top -= 1; low += B104; }
+        else { top = P4 - 1; low += B104 + 1; }         // value was negative: add p
+    }
+    if (low >= B104) { top += 1; low -= B104; }
+    if (top == P4 && low >= 1) { top = 0; low -= 1; }   // value >= p: subtract p
+    return from_u128(((unsigned __int128)(uint64_t)top << 104) | (unsigned __int128)low);
+}
+
+// limbs of a mont_mul5 result (or any normalised vector) -> canonical 128 bits
+STARK_HD fe pack_fast(const fe5& r)
+{
+    const uint32_t l0 = (uint32_t)r.l[0], l1 = (uint32_t)r.l[1], l2 = (uint32_t)r.l[2], l3 = (uint32_t)r.l[3],
+                   l4 = (uint32_t)r.l[4];
+    const uint32_t w0 = (l1 << 26) | l0;
+    const uint32_t w1 = (l2 << 20) | (l1 >> 6);
+    const uint32_t w2 = (l3 << 14) | (l2 >> 12);
+    const uint32_t w3 = (l4 << 8) | (l3 >> 18);
+    return fe{((uint64_t)w1 << 32) | w0, ((uint64_t)w3 << 32) | w2};
+}
+
+// nonzero when r (a mont_mul5 result) is NOT already a canonical normalised
+// vector: low limb overflowed its 26 bits, or the top limb is outside [0, P4).
+STARK_HD uint32_t noncanonical5(const fe5& r)
+{
+    return ((uint32_t)r.l[0] >> LIMB_BITS) | (uint32_t)((uint32_t)r.l[4] >= (uint32_t)P4);
+}
+
+STARK_HD fe pack_canonical(const fe5& r)
+{
+    if (noncanonical5(r)) return reduce5_slow(r);
+    return pack_fast(r);
+}
+
+}  // namespace starkf

@@ -7,10 +7,12 @@
 
 #include "blake2b.hpp"
 #include "field.hpp"
+#include "field5.hpp"
 
 namespace starkk {
 
 using starkf::fe;
+using starkf::tw5;
 using starkh::digest;
 
 constexpr int TILE_ELEMS = 4096;      // elements per workgroup tile
@@ -23,22 +25,26 @@ constexpr int MAX_PASSES = 4;
 struct PassArgs {
     const fe* src;
     fe* dst;
-    const fe* tw16;        // omega_16^i, i<8 (Montgomery form)
-    const fe* tw256;       // omega_256^i, i<256 (Montgomery form)
-    const fe* hi;          // omega_n^(i << h), i < n >> h (Montgomery form)
-    const fe* lo;          // omega_n^i, i < 2^h (Montgomery form; times n^-1 for the inverse)
-    const fe* twist_hi;    // s^(256 i) (Montgomery form), first pass of a coset transform
-    const fe* twist_lo;    // s^i, i<256
+    const tw5* tw16;       // omega_16^i, i<8
+    const tw5* tw256;      // omega_256^i, i<256
+    const tw5* hi;         // omega_n^(i << h), i < n >> h
+    const tw5* lo;         // omega_n^i, i < 2^h
+    const tw5* fin;        // 1 (forward) or n^-1 (inverse): multiplier of the last pass's outputs
+    const tw5* twist_hi;   // s^(256 i), first pass of a coset transform
+    const tw5* twist_lo;   // s^i, i<256
     uint64_t src_batch_stride;   // elements between consecutive transforms of a batch
     uint64_t dst_batch_stride;
     uint64_t n_src;        // valid source elements (first pass zero-fills the rest)
     uint32_t log_n;
     uint32_t log_s;        // log2 S_q
+    uint32_t log_s_next;   // log2 S_{q+1} (unused by the last pass)
+    uint32_t next_is_last; // 1 when pass q+1 is the last pass
     uint32_t r;            // log2 R_q (5..8)
     uint32_t h;            // log2 of the last radix
     uint32_t nprev;        // q
     uint32_t rprev[MAX_PASSES];   // log2 R_u, u < q
 };
+// All tw5 tables hold Montgomery forms w * 2^156 mod p as five 26-bit limbs.
 
 enum PassMode { PASS_FIRST = 0, PASS_MIDDLE = 1, PASS_LAST = 2 };
 

@@ -13,6 +13,7 @@
 // coefficients of the first pass, and the padding zeros are never read.
 #include <hip/hip_runtime.h>
 
+#include "field5.hpp"
 #include "internal.hpp"
 
 namespace starkk {
@@ -26,12 +27,13 @@ __device__ __forceinline__ constexpr int brev_c(int k, int bits)
     return r;
 }
 
-// In-register decimation-in-frequency transform of M = 2^LOGM values at
+// In-register decimation-in-frequency transform of M = 2^LOGM lazy elements at
 // v[BASE .. BASE+M): natural order in, bit-reversed order out (output k sits in
-// register BASE + brev(k)).  tw16[i] = w_16^i in Montgomery form; the index is
-// a compile-time constant after unrolling, so the loads are scalar.
+// register BASE + brev(k)).  Adds and subtracts are carry-free limb operations;
+// only the twiddle products reduce.  tw16[i] = w_16^i (Montgomery form, 2^156);
+// the index is a compile-time constant after unrolling, so the loads are scalar.
 template <int LOGM, int BASE>
-__device__ __forceinline__ void ntt_dif_reg(fe (&v)[16], const fe* __restrict__ tw16)
+__device__ __forceinline__ void ntt_dif_reg(fe5 (&v)[16], const tw5* __restrict__ tw16)
 {
     constexpr int M = 1 << LOGM;
 #pragma unroll
@@ -42,12 +44,12 @@ __device__ __forceinline__ void ntt_dif_reg(fe (&v)[16], const fe* __restrict__ 
         for (int s = 0; s < M; s += len) {
 #pragma unroll
             for (int j = 0; j < half; j++) {
-                fe a = v[BASE + s + j];
-                fe b = v[BASE + s + j + half];
-                v[BASE + s + j] = fe_add(a, b);
-                fe d = fe_sub(a, b);
+                const fe5 a = v[BASE + s + j];
+                const fe5 b = v[BASE + s + j + half];
+                v[BASE + s + j] = add5(a, b);
+                const fe5 d = sub5(a, b);
                 const int e = j * (16 / len);
-                v[BASE + s + j + half] = (e == 0) ? d : mont_mul(d, tw16[e]);
+                v[BASE + s + j + half] = (e == 0) ? d : mont_mul5(d, tw16[e]);
             }
         }
     }
@@ -55,7 +57,7 @@ __device__ __forceinline__ void ntt_dif_reg(fe (&v)[16], const fe* __restrict__ 
 
 template <int LOGM, int G>
 struct RoundOne {
-    __device__ __forceinline__ static void run(fe (&v)[16], const fe* __restrict__ tw16)
+    __device__ __forceinline__ static void run(fe5 (&v)[16], const tw5* __restrict__ tw16)
     {
         ntt_dif_reg<LOGM, (G - 1) * (1 << LOGM)>(v, tw16);
         RoundOne<LOGM, G - 1>::run(v, tw16);
@@ -63,7 +65,7 @@ struct RoundOne {
 };
 template <int LOGM>
 struct RoundOne<LOGM, 0> {
-    __device__ __forceinline__ static void run(fe (&)[16], const fe* __restrict__) {}
+    __device__ __forceinline__ static void run(fe5 (&)[16], const tw5* __restrict__) {}
 };
 
 // memory prefix (k_0 most significant) -> K = k_0 + R_0 k_1 + ...
@@ -93,10 +95,22 @@ __device__ __forceinline__ uint32_t k_to_prefix(uint32_t K, const PassArgs& a)
     return pre;
 }
 
-// RA = log2(R) - 4.  MODE: PASS_FIRST (optional coset twist, zero fill),
-// PASS_MIDDLE (twiddle from hi table), PASS_LAST (rows contiguous, twiddle
-// hi*lo, transposed store to natural order).
-template <int RA, int MODE, bool TWIST>
+// lazy element -> canonical 128-bit value (the slow path is rare: it is taken
+// when the reduced value came out as p + small or small negative)
+__device__ __forceinline__ fe finish(const fe5& x)
+{
+    fe o = pack_fast(x);
+    if (__builtin_expect(noncanonical5(x) != 0, 0)) o = reduce5_slow(x);
+    return o;
+}
+
+// RA = log2(R) - 4.  MODE: PASS_FIRST (strided columns, optional coset twist,
+// zero fill), PASS_MIDDLE (strided columns), PASS_LAST (contiguous rows,
+// transposed store to natural order).  The twiddle that the NEXT pass needs is
+// applied to this pass's outputs, so every element leaves the pass through a
+// multiplication, which is what brings the lazy limbs back to a canonical
+// value; the last pass multiplies by `fin` (1, or n^-1 for the inverse).
+template <int RA, int MODE, bool TWIST, bool NEXT_LAST>
 __global__ __launch_bounds__(TILE_THREADS) void ntt_pass_kernel(PassArgs a)
 {
     constexpr int M1 = 1 << RA;          // round-1 radix
@@ -108,18 +122,18 @@ __global__ __launch_bounds__(TILE_THREADS) void ntt_pass_kernel(PassArgs a)
     constexpr int TWSHIFT = 8 - (RA + 4);
 
     __shared__ fe lds[R * PITCH];
-    __shared__ fe s_tw256[256];
+    __shared__ tw5 s_tw256[256];
 
     const int t = threadIdx.x;
     const fe* __restrict__ src = a.src + (uint64_t)blockIdx.y * a.src_batch_stride;
     fe* __restrict__ dst = a.dst + (uint64_t)blockIdx.y * a.dst_batch_stride;
-    const fe* __restrict__ tw16 = a.tw16;
+    const tw5* __restrict__ tw16 = a.tw16;
 
     s_tw256[t] = a.tw256[t];
 
-    fe v[16];
+    fe5 v[16];
 
-    // ---- load + pass twiddle -------------------------------------------------
+    // ---- load ------------------------------------------------------------------
 #pragma unroll
     for (int g = 0; g < G1; g++) {
         const int q1 = t + TILE_THREADS * g;
@@ -128,37 +142,28 @@ __global__ __launch_bounds__(TILE_THREADS) void ntt_pass_kernel(PassArgs a)
             const uint32_t b = blockIdx.x * C + c;                 // low part of the output index
             const uint64_t row = (uint64_t)k_to_prefix(b, a) << a.r;
 #pragma unroll
-            for (int ja = 0; ja < M1; ja++) {
-                const uint32_t j = ja * 16 + jb;
-                fe x = src[row + j];
-                const uint32_t E = j * b;                          // < n
-                fe w = mont_mul(a.hi[E >> a.h], a.lo[E & (R - 1)]);
-                v[g * M1 + ja] = mont_mul(x, w);
-            }
+            for (int ja = 0; ja < M1; ja++) v[g * M1 + ja] = unpack5(src[row + ja * 16 + jb]);
         } else {
             const int jb = q1 >> LOGC, c = q1 & (C - 1);
             const uint64_t f = (uint64_t)blockIdx.x * C + c;       // flat column of this pass
-            const uint32_t pre = (uint32_t)(f >> a.log_s);
+            const uint64_t pre = f >> a.log_s;
             const uint64_t col = f & (((uint64_t)1 << a.log_s) - 1);
-            const uint64_t base = ((uint64_t)pre << (a.r + a.log_s)) + col;
-            uint32_t ks = 0;
-            if constexpr (MODE == PASS_MIDDLE) ks = prefix_to_k(pre, a) << (a.log_s - a.h);
+            const uint64_t base = (pre << (a.r + a.log_s)) + col;
 #pragma unroll
             for (int ja = 0; ja < M1; ja++) {
                 const uint32_t j = ja * 16 + jb;
                 const uint64_t idx = base + ((uint64_t)j << a.log_s);
-                fe x;
                 if constexpr (MODE == PASS_FIRST) {
-                    x = fe_zero();
+                    fe5 x = {{0, 0, 0, 0, 0}};
                     if (idx < a.n_src) {
-                        x = src[idx];
+                        x = unpack5(src[idx]);
                         if constexpr (TWIST)
-                            x = mont_mul(mont_mul(x, a.twist_lo[idx & 255]), a.twist_hi[idx >> 8]);
+                            x = mont_mul5(x, mont_mul5(*(const fe5*)&a.twist_hi[idx >> 8], a.twist_lo[idx & 255]));
                     }
+                    v[g * M1 + ja] = x;
                 } else {
-                    x = mont_mul(src[idx], a.hi[j * ks]);
+                    v[g * M1 + ja] = unpack5(src[idx]);
                 }
-                v[g * M1 + ja] = x;
             }
         }
     }
@@ -178,9 +183,8 @@ __global__ __launch_bounds__(TILE_THREADS) void ntt_pass_kernel(PassArgs a)
 #pragma unroll
         for (int ka = 0; ka < M1; ka++) {
             const int reg = g * M1 + brev_c(ka, RA);
-            fe x = v[reg];
-            if (ka != 0) x = mont_mul(x, s_tw256[(jb * ka) << TWSHIFT]);
-            lds[(ka * 16 + jb) * PITCH + c] = x;
+            const fe5 x = mont_mul5(v[reg], s_tw256[(jb * ka) << TWSHIFT]);
+            lds[(ka * 16 + jb) * PITCH + c] = finish(x);
         }
     }
 
@@ -189,49 +193,73 @@ __global__ __launch_bounds__(TILE_THREADS) void ntt_pass_kernel(PassArgs a)
     // ---- round 2: radix 16 over jb ----------------------------------------------
     const int ka2 = t >> LOGC, c2 = t & (C - 1);
 #pragma unroll
-    for (int jb = 0; jb < 16; jb++) v[jb] = lds[(ka2 * 16 + jb) * PITCH + c2];
+    for (int jb = 0; jb < 16; jb++) v[jb] = unpack5(lds[(ka2 * 16 + jb) * PITCH + c2]);
 
     ntt_dif_reg<4, 0>(v, tw16);
 
-    // ---- store ----------------------------------------------------------------
+    // ---- outgoing twiddle + store ------------------------------------------------
     if constexpr (MODE == PASS_LAST) {
         const uint64_t b = (uint64_t)blockIdx.x * C + c2;
         const uint32_t sh = a.log_n - a.r;
+        const tw5 fin = *a.fin;
 #pragma unroll
         for (int kb = 0; kb < 16; kb++) {
             const uint64_t k = ka2 + M1 * kb;
-            dst[(k << sh) + b] = v[brev_c(kb, 4)];
+            dst[(k << sh) + b] = finish(mont_mul5(v[brev_c(kb, 4)], fin));
         }
     } else {
         const uint64_t f = (uint64_t)blockIdx.x * C + c2;
-        const uint64_t pre = f >> a.log_s;
+        const uint32_t pre = (uint32_t)(f >> a.log_s);
         const uint64_t col = f & (((uint64_t)1 << a.log_s) - 1);
-        const uint64_t base = (pre << (a.r + a.log_s)) + col;
+        const uint64_t base = ((uint64_t)pre << (a.r + a.log_s)) + col;
+        // twiddle of the next pass: w_n^(j_next * K * S_next), K = K_prev + k * 2^bits_prev
+        const uint32_t j_next = (uint32_t)(col >> a.log_s_next);
+        uint32_t bits_prev = 0;
+        for (uint32_t u = 0; u < a.nprev; u++) bits_prev += a.rprev[u];
+        const uint32_t k_prev = prefix_to_k(pre, a);
+        if constexpr (NEXT_LAST) {
+            // S_next = 1: exponent j_next * K, split over the hi and lo tables
+#pragma clang loop unroll(full)
+            for (int kb = 0; kb < 16; kb++) {
+                const uint32_t k = ka2 + M1 * kb;
+                const uint32_t E = j_next * (k_prev + (k << bits_prev));
+                const fe5 w = mont_mul5(*(const fe5*)&a.hi[E >> a.h], a.lo[E & ((1u << a.h) - 1)]);
+                dst[base + ((uint64_t)k << a.log_s)] = finish(mont_mul5(v[brev_c(kb, 4)], w));
+            }
+        } else {
+            const uint32_t sn = a.log_s_next - a.h;                // S_next / 2^h
 #pragma unroll
-        for (int kb = 0; kb < 16; kb++) {
-            const uint64_t k = ka2 + M1 * kb;
-            dst[base + (k << a.log_s)] = v[brev_c(kb, 4)];
+            for (int kb = 0; kb < 16; kb++) {
+                const uint32_t k = ka2 + M1 * kb;
+                const uint32_t E = (j_next * (k_prev + (k << bits_prev))) << sn;
+                dst[base + ((uint64_t)k << a.log_s)] = finish(mont_mul5(v[brev_c(kb, 4)], a.hi[E]));
+            }
         }
     }
 }
 
-template <int RA, int MODE, bool TWIST>
+template <int RA, int MODE, bool TWIST, bool NEXT_LAST>
 static hipError_t launch_one(const PassArgs& a, uint32_t n_batch, hipStream_t s)
 {
     dim3 grid((uint32_t)(((uint64_t)1 << a.log_n) / TILE_ELEMS), n_batch, 1);
-    hipLaunchKernelGGL((ntt_pass_kernel<RA, MODE, TWIST>), grid, dim3(TILE_THREADS), 0, s, a);
+    hipLaunchKernelGGL((ntt_pass_kernel<RA, MODE, TWIST, NEXT_LAST>), grid, dim3(TILE_THREADS), 0, s, a);
     return hipGetLastError();
 }
 
 template <int RA>
 static hipError_t launch_ra(const PassArgs& a, PassMode mode, bool twist, uint32_t n_batch, hipStream_t s)
 {
+    const bool nl = a.next_is_last != 0;
     switch (mode) {
     case PASS_FIRST:
-        return twist ? launch_one<RA, PASS_FIRST, true>(a, n_batch, s)
-                     : launch_one<RA, PASS_FIRST, false>(a, n_batch, s);
-    case PASS_MIDDLE: return launch_one<RA, PASS_MIDDLE, false>(a, n_batch, s);
-    case PASS_LAST: return launch_one<RA, PASS_LAST, false>(a, n_batch, s);
+        if (twist) return nl ? launch_one<RA, PASS_FIRST, true, true>(a, n_batch, s)
+                             : launch_one<RA, PASS_FIRST, true, false>(a, n_batch, s);
+        return nl ? launch_one<RA, PASS_FIRST, false, true>(a, n_batch, s)
+                  : launch_one<RA, PASS_FIRST, false, false>(a, n_batch, s);
+    case PASS_MIDDLE:
+        return nl ? launch_one<RA, PASS_MIDDLE, false, true>(a, n_batch, s)
+                  : launch_one<RA, PASS_MIDDLE, false, false>(a, n_batch, s);
+    case PASS_LAST: return launch_one<RA, PASS_LAST, false, false>(a, n_batch, s);
     }
     return hipErrorInvalidValue;
 }

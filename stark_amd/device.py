@@ -147,7 +147,11 @@ class Context:
             self.h = None
 
     def set_stream(self, hip_stream: Optional[int]):
-        self._chk(self.lib.stark_ctx_set_stream(self.h, hip_stream))
+        """Launch on the caller's stream (None / 0 = HIP's default stream)."""
+        self._chk(self.lib.stark_ctx_set_stream(self.h, hip_stream or None))
+
+    def reset_stream(self):
+        self._chk(self.lib.stark_ctx_reset_stream(self.h))
 
     def synchronize(self):
         self._chk(self.lib.stark_ctx_synchronize(self.h))
