@@ -146,6 +146,95 @@ STARK_HD fe5 mont_mul5(const fe5& a, const W& w)
     return r;
 }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// Hand-scheduled form of mont_mul5 for the device: one serial column chain on a
+// fixed accumulator pair (v[254:255]), 31 v_mad_i64_i32 + 10 v_and + 10
+// v_ashrrev_i64.  hipcc re-associates the C++ form into "sum the column's
+// products, then add the carry", which costs one more 64-bit add per column.
+// WS selects where the twiddle limbs live: "s" (wave-uniform, scalar registers)
+// or "v".  VOP3 reads at most one scalar operand, which every line respects.
+#define STARK_MM5_BODY                                            \
+    "v_mad_i64_i32 v[254:255], vcc, %[a0], %[w0], 0\n\t"          \
+    "v_and_b32 %[m0], 0x3ffffff, v254\n\t"                        \
+    "v_ashrrev_i64 v[254:255], 26, v[254:255]\n\t"                \
+    "v_mad_i64_i32 v[254:255], vcc, %[a0], %[w1], v[254:255]\n\t" \
+    "v_mad_i64_i32 v[254:255], vcc, %[a1], %[w0], v[254:255]\n\t" \
+    "v_and_b32 %[m1], 0x3ffffff, v254\n\t"                        \
+    "v_ashrrev_i64 v[254:255], 26, v[254:255]\n\t"                \
+    "v_mad_i64_i32 v[254:255], vcc, %[a0], %[w2], v[254:255]\n\t" \
+    "v_mad_i64_i32 v[254:255], vcc, %[a1], %[w1], v[254:255]\n\t" \
+    "v_mad_i64_i32 v[254:255], vcc, %[a2], %[w0], v[254:255]\n\t" \
+    "v_and_b32 %[m2], 0x3ffffff, v254\n\t"                        \
+    "v_ashrrev_i64 v[254:255], 26, v[254:255]\n\t"                \
+    "v_mad_i64_i32 v[254:255], vcc, %[a0], %[w3], v[254:255]\n\t" \
+    "v_mad_i64_i32 v[254:255], vcc, %[a1], %[w2], v[254:255]\n\t" \
+    "v_mad_i64_i32 v[254:255], vcc, %[a2], %[w1], v[254:255]\n\t" \
+    "v_mad_i64_i32 v[254:255], vcc, %[a3], %[w0], v[254:255]\n\t" \
+    "v_and_b32 %[m3], 0x3ffffff, v254\n\t"                        \
+    "v_ashrrev_i64 v[254:255], 26, v[254:255]\n\t"                \
+    "v_mad_i64_i32 v[254:255], vcc, %[a0], %[w4], v[254:255]\n\t" \
+    "v_mad_i64_i32 v[254:255], vcc, %[a1], %[w3], v[254:255]\n\t" \
+    "v_mad_i64_i32 v[254:255], vcc, %[a2], %[w2], v[254:255]\n\t" \
+    "v_mad_i64_i32 v[254:255], vcc, %[a3], %[w1], v[254:255]\n\t" \
+    "v_mad_i64_i32 v[254:255], vcc, %[a4], %[w0], v[254:255]\n\t" \
+    "v_mad_i64_i32 v[254:255], vcc, %[m0], %[np4], v[254:255]\n\t" \
+    "v_and_b32 %[m0], 0x3ffffff, v254\n\t"                        \
+    "v_ashrrev_i64 v[254:255], 26, v[254:255]\n\t"                \
+    "v_mad_i64_i32 v[254:255], vcc, %[a1], %[w4], v[254:255]\n\t" \
+    "v_mad_i64_i32 v[254:255], vcc, %[a2], %[w3], v[254:255]\n\t" \
+    "v_mad_i64_i32 v[254:255], vcc, %[a3], %[w2], v[254:255]\n\t" \
+    "v_mad_i64_i32 v[254:255], vcc, %[a4], %[w1], v[254:255]\n\t" \
+    "v_mad_i64_i32 v[254:255], vcc, %[m1], %[np4], v[254:255]\n\t" \
+    "v_and_b32 %[m1], 0x3ffffff, v254\n\t"                        \
+    "v_ashrrev_i64 v[254:255], 26, v[254:255]\n\t"                \
+    "v_mad_i64_i32 v[254:255], vcc, %[a2], %[w4], v[254:255]\n\t" \
+    "v_mad_i64_i32 v[254:255], vcc, %[a3], %[w3], v[254:255]\n\t" \
+    "v_mad_i64_i32 v[254:255], vcc, %[a4], %[w2], v[254:255]\n\t" \
+    "v_mad_i64_i32 v[254:255], vcc, %[m2], %[np4], v[254:255]\n\t" \
+    "v_and_b32 %[r0], 0x3ffffff, v254\n\t"                        \
+    "v_ashrrev_i64 v[254:255], 26, v[254:255]\n\t"                \
+    "v_mad_i64_i32 v[254:255], vcc, %[a3], %[w4], v[254:255]\n\t" \
+    "v_mad_i64_i32 v[254:255], vcc, %[a4], %[w3], v[254:255]\n\t" \
+    "v_mad_i64_i32 v[254:255], vcc, %[m3], %[np4], v[254:255]\n\t" \
+    "v_and_b32 %[r1], 0x3ffffff, v254\n\t"                        \
+    "v_ashrrev_i64 v[254:255], 26, v[254:255]\n\t"                \
+    "v_mad_i64_i32 v[254:255], vcc, %[a4], %[w4], v[254:255]\n\t" \
+    "v_mad_i64_i32 v[254:255], vcc, %[m0], %[np4], v[254:255]\n\t" \
+    "v_and_b32 %[r2], 0x3ffffff, v254\n\t"                        \
+    "v_ashrrev_i64 v[254:255], 26, v[254:255]\n\t"                \
+    "v_mad_i64_i32 v[254:255], vcc, %[m1], %[np4], v[254:255]\n\t" \
+    "v_and_b32 %[r3], 0x3ffffff, v254\n\t"                        \
+    "v_ashrrev_i64 v[254:255], 26, v[254:255]\n\t"                \
+    "v_mov_b32 %[r4], v254"
+
+#define STARK_MM5_DEFINE(NAME, WS)                                                                            \
+    template <class W>                                                                                        \
+    __device__ __forceinline__ fe5 NAME(const fe5& a, const W& w)                                             \
+    {                                                                                                         \
+        int32_t r0, r1, r2, r3, r4, m0, m1, m2, m3;                                                           \
+        asm(STARK_MM5_BODY                                                                                    \
+            : [r0] "=&v"(r0), [r1] "=&v"(r1), [r2] "=&v"(r2), [r3] "=&v"(r3), [r4] "=&v"(r4), [m0] "=&v"(m0), \
+              [m1] "=&v"(m1), [m2] "=&v"(m2), [m3] "=&v"(m3)                                                  \
+            : [a0] "v"(a.l[0]), [a1] "v"(a.l[1]), [a2] "v"(a.l[2]), [a3] "v"(a.l[3]), [a4] "v"(a.l[4]),       \
+              [w0] WS(w.l[0]), [w1] WS(w.l[1]), [w2] WS(w.l[2]), [w3] WS(w.l[3]), [w4] WS(w.l[4]),            \
+              [np4] "s"(-P4)                                                                                  \
+            : "vcc", "v254", "v255");                                                                         \
+        fe5 r;                                                                                                \
+        r.l[0] = r0 + 1;                                                                                      \
+        r.l[1] = r1;                                                                                          \
+        r.l[2] = r2;                                                                                          \
+        r.l[3] = r3;                                                                                          \
+        r.l[4] = r4 + P4;                                                                                     \
+        return r;                                                                                             \
+    }
+STARK_MM5_DEFINE(mont_mul5_v, "v")   // twiddle limbs in vector registers
+STARK_MM5_DEFINE(mont_mul5_s, "s")   // twiddle limbs wave-uniform, in scalar registers
+#undef STARK_MM5_DEFINE
+#else
+template <class W> STARK_HD fe5 mont_mul5_v(const fe5& a, const W& w) { return mont_mul5(a, w); }
+template <class W> STARK_HD fe5 mont_mul5_s(const fe5& a, const W& w) { return mont_mul5(a, w); }
+#endif
+
 // Exact reduction of any limb vector with |value| < 2^150 into [0, p); the slow
 // path behind pack_canonical.
 STARK_HD fe reduce5_slow(const fe5& r)

@@ -49,7 +49,7 @@ __device__ __forceinline__ void ntt_dif_reg(fe5 (&v)[16], const tw5* __restrict_
                 v[BASE + s + j] = add5(a, b);
                 const fe5 d = sub5(a, b);
                 const int e = j * (16 / len);
-                v[BASE + s + j + half] = (e == 0) ? d : mont_mul5(d, tw16[e]);
+                v[BASE + s + j + half] = (e == 0) ? d : mont_mul5_s(d, tw16[e]);
             }
         }
     }
@@ -95,6 +95,14 @@ __device__ __forceinline__ uint32_t k_to_prefix(uint32_t K, const PassArgs& a)
     return pre;
 }
 
+// Workgroup barrier for LDS hand-offs only.  __syncthreads() also drains the
+// vector-memory counter (vmcnt(0)); only LDS traffic has to be ordered here,
+// so loads and stores in flight may stay in flight across the barrier.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // lazy element -> canonical 128-bit value (the slow path is rare: it is taken
 // when the reduced value came out as p + small or small negative)
 __device__ __forceinline__ fe finish(const fe5& x)
@@ -104,14 +112,62 @@ __device__ __forceinline__ fe finish(const fe5& x)
     return o;
 }
 
+// Issue the 16 global loads of one thread for one tile (round-1 layout).
+// tile enumerates (batch, tile-in-transform); rows past n_src of a first pass
+// are the zero padding and are not read.
+template <int RA, int MODE>
+__device__ __forceinline__ void load_tile(fe (&raw)[16], const PassArgs& a, uint64_t tile, int t)
+{
+    constexpr int M1 = 1 << RA;
+    constexpr int G1 = 16 / M1;
+    constexpr int LOGC = 8 - RA;
+    constexpr int C = 1 << LOGC;
+    const uint32_t ltiles = a.log_n - 12;
+    const uint64_t batch = tile >> ltiles;
+    const uint32_t tx = (uint32_t)(tile & (((uint64_t)1 << ltiles) - 1));
+    const fe* __restrict__ src = a.src + batch * a.src_batch_stride;
+#pragma unroll
+    for (int g = 0; g < G1; g++) {
+        const int q1 = t + TILE_THREADS * g;
+        if constexpr (MODE == PASS_LAST) {
+            const int c = q1 >> 4, jb = q1 & 15;
+            const uint32_t b = tx * C + c;                         // low part of the output index
+            const uint64_t row = (uint64_t)k_to_prefix(b, a) << a.r;
+#pragma unroll
+            for (int ja = 0; ja < M1; ja++) raw[g * M1 + ja] = src[row + ja * 16 + jb];
+        } else {
+            const int jb = q1 >> LOGC, c = q1 & (C - 1);
+            const uint64_t f = (uint64_t)tx * C + c;               // flat column of this pass
+            const uint64_t pre = f >> a.log_s;
+            const uint64_t col = f & (((uint64_t)1 << a.log_s) - 1);
+            const uint64_t base = (pre << (a.r + a.log_s)) + col;
+#pragma unroll
+            for (int ja = 0; ja < M1; ja++) {
+                const uint64_t idx = base + ((uint64_t)(ja * 16 + jb) << a.log_s);
+                if constexpr (MODE == PASS_FIRST) {
+                    raw[g * M1 + ja] = fe_zero();
+                    if (idx < a.n_src) raw[g * M1 + ja] = src[idx];
+                } else {
+                    raw[g * M1 + ja] = src[idx];
+                }
+            }
+        }
+    }
+}
+
 // RA = log2(R) - 4.  MODE: PASS_FIRST (strided columns, optional coset twist,
 // zero fill), PASS_MIDDLE (strided columns), PASS_LAST (contiguous rows,
 // transposed store to natural order).  The twiddle that the NEXT pass needs is
 // applied to this pass's outputs, so every element leaves the pass through a
 // multiplication, which is what brings the lazy limbs back to a canonical
 // value; the last pass multiplies by `fin` (1, or n^-1 for the inverse).
+// One workgroup per tile: two workgroups are resident per CU (LDS- and
+// register-limited), and it is the second one that hides the first one's
+// global-memory latency.  (A persistent loop that prefetched the next tile into
+// registers was measured slower: the extra 64 registers spill, and a spill
+// reload's vmcnt wait drains the prefetch.)
 template <int RA, int MODE, bool TWIST, bool NEXT_LAST>
-__global__ __launch_bounds__(TILE_THREADS) void ntt_pass_kernel(PassArgs a)
+__global__ __launch_bounds__(TILE_THREADS) void ntt_pass_kernel(PassArgs a, uint64_t total_tiles)
 {
     constexpr int M1 = 1 << RA;          // round-1 radix
     constexpr int G1 = 16 / M1;          // round-1 groups per thread
@@ -125,114 +181,111 @@ __global__ __launch_bounds__(TILE_THREADS) void ntt_pass_kernel(PassArgs a)
     __shared__ tw5 s_tw256[256];
 
     const int t = threadIdx.x;
-    const fe* __restrict__ src = a.src + (uint64_t)blockIdx.y * a.src_batch_stride;
-    fe* __restrict__ dst = a.dst + (uint64_t)blockIdx.y * a.dst_batch_stride;
     const tw5* __restrict__ tw16 = a.tw16;
+    const uint32_t ltiles = a.log_n - 12;
 
     s_tw256[t] = a.tw256[t];
 
+    fe raw[16];
     fe5 v[16];
 
-    // ---- load ------------------------------------------------------------------
+    const uint64_t tile = blockIdx.x;
+    load_tile<RA, MODE>(raw, a, tile, t);
+    (void)total_tiles;
+
+    {
+        const uint64_t batch = tile >> ltiles;
+        const uint32_t tx = (uint32_t)(tile & (((uint64_t)1 << ltiles) - 1));
+        fe* __restrict__ dst = a.dst + batch * a.dst_batch_stride;
+
+        // ---- unpack (and coset twist) ----------------------------------------------
 #pragma unroll
-    for (int g = 0; g < G1; g++) {
-        const int q1 = t + TILE_THREADS * g;
-        if constexpr (MODE == PASS_LAST) {
-            const int c = q1 >> 4, jb = q1 & 15;
-            const uint32_t b = blockIdx.x * C + c;                 // low part of the output index
-            const uint64_t row = (uint64_t)k_to_prefix(b, a) << a.r;
+        for (int i = 0; i < 16; i++) v[i] = unpack5(raw[i]);
+        if constexpr (MODE == PASS_FIRST && TWIST) {
 #pragma unroll
-            for (int ja = 0; ja < M1; ja++) v[g * M1 + ja] = unpack5(src[row + ja * 16 + jb]);
-        } else {
-            const int jb = q1 >> LOGC, c = q1 & (C - 1);
-            const uint64_t f = (uint64_t)blockIdx.x * C + c;       // flat column of this pass
-            const uint64_t pre = f >> a.log_s;
-            const uint64_t col = f & (((uint64_t)1 << a.log_s) - 1);
-            const uint64_t base = (pre << (a.r + a.log_s)) + col;
+            for (int g = 0; g < G1; g++) {
+                const int q1 = t + TILE_THREADS * g;
+                const int jb = q1 >> LOGC, c = q1 & (C - 1);
+                const uint64_t f = (uint64_t)tx * C + c;
+                const uint64_t pre = f >> a.log_s;
+                const uint64_t col = f & (((uint64_t)1 << a.log_s) - 1);
+                const uint64_t base = (pre << (a.r + a.log_s)) + col;
 #pragma unroll
-            for (int ja = 0; ja < M1; ja++) {
-                const uint32_t j = ja * 16 + jb;
-                const uint64_t idx = base + ((uint64_t)j << a.log_s);
-                if constexpr (MODE == PASS_FIRST) {
-                    fe5 x = {{0, 0, 0, 0, 0}};
-                    if (idx < a.n_src) {
-                        x = unpack5(src[idx]);
-                        if constexpr (TWIST)
-                            x = mont_mul5(x, mont_mul5(*(const fe5*)&a.twist_hi[idx >> 8], a.twist_lo[idx & 255]));
-                    }
-                    v[g * M1 + ja] = x;
-                } else {
-                    v[g * M1 + ja] = unpack5(src[idx]);
+                for (int ja = 0; ja < M1; ja++) {
+                    const uint64_t idx = base + ((uint64_t)(ja * 16 + jb) << a.log_s);
+                    if (idx < a.n_src)
+                        v[g * M1 + ja] = mont_mul5_v(
+                            v[g * M1 + ja], mont_mul5_v(*(const fe5*)&a.twist_hi[idx >> 8], a.twist_lo[idx & 255]));
                 }
             }
         }
-    }
 
-    __syncthreads();            // s_tw256 staged
+        lds_barrier();          // s_tw256 staged
 
-    // ---- round 1: radix M1 over ja ---------------------------------------------
-    RoundOne<RA, G1>::run(v, tw16);
+        // ---- round 1: radix M1 over ja ---------------------------------------------
+        RoundOne<RA, G1>::run(v, tw16);
 
-    // ---- inner twiddle w_R^(jb*ka), exchange through LDS -----------------------
+        // ---- inner twiddle w_R^(jb*ka), exchange through LDS -----------------------
 #pragma unroll
-    for (int g = 0; g < G1; g++) {
-        const int q1 = t + TILE_THREADS * g;
-        int jb, c;
-        if constexpr (MODE == PASS_LAST) { c = q1 >> 4; jb = q1 & 15; }
-        else { jb = q1 >> LOGC; c = q1 & (C - 1); }
+        for (int g = 0; g < G1; g++) {
+            const int q1 = t + TILE_THREADS * g;
+            int jb, c;
+            if constexpr (MODE == PASS_LAST) { c = q1 >> 4; jb = q1 & 15; }
+            else { jb = q1 >> LOGC; c = q1 & (C - 1); }
 #pragma unroll
-        for (int ka = 0; ka < M1; ka++) {
-            const int reg = g * M1 + brev_c(ka, RA);
-            const fe5 x = mont_mul5(v[reg], s_tw256[(jb * ka) << TWSHIFT]);
-            lds[(ka * 16 + jb) * PITCH + c] = finish(x);
+            for (int ka = 0; ka < M1; ka++) {
+                const int reg = g * M1 + brev_c(ka, RA);
+                const fe5 x = mont_mul5_v(v[reg], s_tw256[(jb * ka) << TWSHIFT]);
+                lds[(ka * 16 + jb) * PITCH + c] = finish(x);
+            }
         }
-    }
 
-    __syncthreads();
+        lds_barrier();
 
-    // ---- round 2: radix 16 over jb ----------------------------------------------
-    const int ka2 = t >> LOGC, c2 = t & (C - 1);
+        // ---- round 2: radix 16 over jb ----------------------------------------------
+        const int ka2 = t >> LOGC, c2 = t & (C - 1);
 #pragma unroll
-    for (int jb = 0; jb < 16; jb++) v[jb] = unpack5(lds[(ka2 * 16 + jb) * PITCH + c2]);
+        for (int jb = 0; jb < 16; jb++) v[jb] = unpack5(lds[(ka2 * 16 + jb) * PITCH + c2]);
 
-    ntt_dif_reg<4, 0>(v, tw16);
+        ntt_dif_reg<4, 0>(v, tw16);
 
-    // ---- outgoing twiddle + store ------------------------------------------------
-    if constexpr (MODE == PASS_LAST) {
-        const uint64_t b = (uint64_t)blockIdx.x * C + c2;
-        const uint32_t sh = a.log_n - a.r;
-        const tw5 fin = *a.fin;
+        // ---- outgoing twiddle + store ------------------------------------------------
+        if constexpr (MODE == PASS_LAST) {
+            const uint64_t b = (uint64_t)tx * C + c2;
+            const uint32_t sh = a.log_n - a.r;
+            const tw5 fin = *a.fin;
 #pragma unroll
-        for (int kb = 0; kb < 16; kb++) {
-            const uint64_t k = ka2 + M1 * kb;
-            dst[(k << sh) + b] = finish(mont_mul5(v[brev_c(kb, 4)], fin));
-        }
-    } else {
-        const uint64_t f = (uint64_t)blockIdx.x * C + c2;
-        const uint32_t pre = (uint32_t)(f >> a.log_s);
-        const uint64_t col = f & (((uint64_t)1 << a.log_s) - 1);
-        const uint64_t base = ((uint64_t)pre << (a.r + a.log_s)) + col;
-        // twiddle of the next pass: w_n^(j_next * K * S_next), K = K_prev + k * 2^bits_prev
-        const uint32_t j_next = (uint32_t)(col >> a.log_s_next);
-        uint32_t bits_prev = 0;
-        for (uint32_t u = 0; u < a.nprev; u++) bits_prev += a.rprev[u];
-        const uint32_t k_prev = prefix_to_k(pre, a);
-        if constexpr (NEXT_LAST) {
-            // S_next = 1: exponent j_next * K, split over the hi and lo tables
-#pragma clang loop unroll(full)
             for (int kb = 0; kb < 16; kb++) {
-                const uint32_t k = ka2 + M1 * kb;
-                const uint32_t E = j_next * (k_prev + (k << bits_prev));
-                const fe5 w = mont_mul5(*(const fe5*)&a.hi[E >> a.h], a.lo[E & ((1u << a.h) - 1)]);
-                dst[base + ((uint64_t)k << a.log_s)] = finish(mont_mul5(v[brev_c(kb, 4)], w));
+                const uint64_t k = ka2 + M1 * kb;
+                dst[(k << sh) + b] = finish(mont_mul5_s(v[brev_c(kb, 4)], fin));
             }
         } else {
-            const uint32_t sn = a.log_s_next - a.h;                // S_next / 2^h
-#pragma unroll
-            for (int kb = 0; kb < 16; kb++) {
-                const uint32_t k = ka2 + M1 * kb;
-                const uint32_t E = (j_next * (k_prev + (k << bits_prev))) << sn;
-                dst[base + ((uint64_t)k << a.log_s)] = finish(mont_mul5(v[brev_c(kb, 4)], a.hi[E]));
+            const uint64_t f = (uint64_t)tx * C + c2;
+            const uint32_t pre = (uint32_t)(f >> a.log_s);
+            const uint64_t col = f & (((uint64_t)1 << a.log_s) - 1);
+            const uint64_t base = ((uint64_t)pre << (a.r + a.log_s)) + col;
+            // twiddle of the next pass: w_n^(j_next * K * S_next), K = K_prev + k * 2^bits_prev
+            const uint32_t j_next = (uint32_t)(col >> a.log_s_next);
+            uint32_t bits_prev = 0;
+            for (uint32_t u = 0; u < a.nprev; u++) bits_prev += a.rprev[u];
+            const uint32_t k_prev = prefix_to_k(pre, a);
+            if constexpr (NEXT_LAST) {
+                // S_next = 1: exponent j_next * K, split over the hi and lo tables
+#pragma clang loop unroll(full)
+                for (int kb = 0; kb < 16; kb++) {
+                    const uint32_t k = ka2 + M1 * kb;
+                    const uint32_t E = j_next * (k_prev + (k << bits_prev));
+                    const fe5 w = mont_mul5_v(*(const fe5*)&a.hi[E >> a.h], a.lo[E & ((1u << a.h) - 1)]);
+                    dst[base + ((uint64_t)k << a.log_s)] = finish(mont_mul5_v(v[brev_c(kb, 4)], w));
+                }
+            } else {
+                const uint32_t sn = a.log_s_next - a.h;                // S_next / 2^h
+#pragma clang loop unroll(full)
+                for (int kb = 0; kb < 16; kb++) {
+                    const uint32_t k = ka2 + M1 * kb;
+                    const uint32_t E = (j_next * (k_prev + (k << bits_prev))) << sn;
+                    dst[base + ((uint64_t)k << a.log_s)] = finish(mont_mul5_v(v[brev_c(kb, 4)], a.hi[E]));
+                }
             }
         }
     }
@@ -241,8 +294,10 @@ __global__ __launch_bounds__(TILE_THREADS) void ntt_pass_kernel(PassArgs a)
 template <int RA, int MODE, bool TWIST, bool NEXT_LAST>
 static hipError_t launch_one(const PassArgs& a, uint32_t n_batch, hipStream_t s)
 {
-    dim3 grid((uint32_t)(((uint64_t)1 << a.log_n) / TILE_ELEMS), n_batch, 1);
-    hipLaunchKernelGGL((ntt_pass_kernel<RA, MODE, TWIST, NEXT_LAST>), grid, dim3(TILE_THREADS), 0, s, a);
+    const uint64_t total = (((uint64_t)1 << a.log_n) / TILE_ELEMS) * n_batch;
+    if (total > 0x7fffffffull) return hipErrorInvalidValue;
+    const uint32_t grid = (uint32_t)total;
+    hipLaunchKernelGGL((ntt_pass_kernel<RA, MODE, TWIST, NEXT_LAST>), dim3(grid), dim3(TILE_THREADS), 0, s, a, total);
     return hipGetLastError();
 }
 

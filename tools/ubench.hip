@@ -4,7 +4,7 @@
 #include <cstdio>
 #include <cstdint>
 #include <vector>
-#include "../stark_amd/csrc/field.hpp"
+#include "../stark_amd/csrc/field5.hpp"
 
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 
@@ -112,6 +112,27 @@ __global__ __launch_bounds__(256) void probe_addsub(starkf::fe* out, starkf::fe 
     if (r.lo == 0x1234567 && r.hi == 77) out[0] = r;
 }
 
+// mont_mul5 throughput: KIND 0 = C++ form, 1 = asm with vector twiddle, 2 = asm with scalar twiddle
+template <int KIND> __global__ __launch_bounds__(256) void probe_montmul5(int32_t* out, starkf::tw5 wu, const starkf::tw5* wtab)
+{
+    using namespace starkf;
+    fe5 x0, x1, x2, x3;
+    for (int i = 0; i < 5; i++) {
+        x0.l[i] = (int32_t)(threadIdx.x * 2654435761u + i * 40503u + blockIdx.x);
+        x1.l[i] = x0.l[i] ^ 0x1234567; x2.l[i] = x0.l[i] >> 3; x3.l[i] = -x0.l[i];
+    }
+    tw5 wv = wtab[threadIdx.x & 15];
+    for (int it = 0; it < 256; it++) {
+        if constexpr (KIND == 0) { x0 = mont_mul5(x0, wv); x1 = mont_mul5(x1, wv); x2 = mont_mul5(x2, wv); x3 = mont_mul5(x3, wv); }
+        if constexpr (KIND == 1) { x0 = mont_mul5_v(x0, wv); x1 = mont_mul5_v(x1, wv); x2 = mont_mul5_v(x2, wv); x3 = mont_mul5_v(x3, wv); }
+        if constexpr (KIND == 2) { x0 = mont_mul5_s(x0, wu); x1 = mont_mul5_s(x1, wu); x2 = mont_mul5_s(x2, wu); x3 = mont_mul5_s(x3, wu); }
+        if constexpr (KIND == 3) { x0 = mont_mul5(x0, wu); x1 = mont_mul5(x1, wu); x2 = mont_mul5(x2, wu); x3 = mont_mul5(x3, wu); }
+    }
+    fe5 r = add5(add5(x0, x1), add5(x2, x3));
+    int32_t* o = out + ((size_t)blockIdx.x * 256 + threadIdx.x) * 5;
+    for (int i = 0; i < 5; i++) o[i] = r.l[i];
+}
+
 template <int KIND> int run(const char* name, int instr_per_iter, uint64_t* d)
 {
     const int blocks = 256 * 8, threads = 256;
@@ -172,6 +193,49 @@ int main()
         double ops = 5.0 * 2048 * 256 * 1024 * 4;
         printf("fe_add/fe_sub                %8.3f ms  %9.2f Gop/s   ~%6.1f cyc/wave-op/SIMD\n", ms, ops / (ms * 1e-3) / 1e9,
                2.4e9 * 1024 / (ops / 64 / (ms * 1e-3)));
+    }
+    {
+        using namespace starkf;
+        for (int blocks : {2048, 1024, 512, 256}) {
+        printf("-- mont_mul5 with %d blocks of 256 threads (%d waves/SIMD)\n", blocks, blocks / 256);
+        int32_t* o[4]; tw5* wt;
+        for (int k = 0; k < 4; k++) CHECK(hipMalloc(&o[k], (size_t)blocks * 256 * 5 * 4));
+        std::vector<tw5> hw(16);
+        for (int i = 0; i < 16; i++) for (int j = 0; j < 5; j++) hw[i].l[j] = (int32_t)((1103515245u * (i * 5 + j + 1) + 12345u) & (j == 4 ? 0xffffff : 0x3ffffff));
+        CHECK(hipMalloc(&wt, sizeof(tw5) * 16));
+        CHECK(hipMemcpy(wt, hw.data(), sizeof(tw5) * 16, hipMemcpyHostToDevice));
+        tw5 wu = hw[3];
+        hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+        const char* names[4] = {"mont_mul5 C++ (v twiddle)", "mont_mul5 asm (v twiddle)", "mont_mul5 asm (s twiddle)", "mont_mul5 C++ (s twiddle)"};
+        for (int k = 0; k < 4; k++) {
+            auto launch = [&](int kk) {
+                if (kk == 0) hipLaunchKernelGGL(probe_montmul5<0>, dim3(blocks), dim3(256), 0, 0, o[0], wu, wt);
+                if (kk == 1) hipLaunchKernelGGL(probe_montmul5<1>, dim3(blocks), dim3(256), 0, 0, o[1], wu, wt);
+                if (kk == 2) hipLaunchKernelGGL(probe_montmul5<2>, dim3(blocks), dim3(256), 0, 0, o[2], wu, wt);
+                if (kk == 3) hipLaunchKernelGGL(probe_montmul5<3>, dim3(blocks), dim3(256), 0, 0, o[3], wu, wt);
+            };
+            launch(k);
+            CHECK(hipDeviceSynchronize());
+            CHECK(hipEventRecord(e0));
+            for (int r = 0; r < 5; r++) launch(k);
+            CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+            float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+            double muls = 5.0 * blocks * 256 * 256 * 4;
+            printf("%-28s %8.3f ms  %9.2f Gmul/s  ~%6.1f cyc/wave-mul/SIMD\n", names[k], ms, muls / (ms * 1e-3) / 1e9,
+                   2.4e9 * 1024 / (muls / 64 / (ms * 1e-3)));
+        }
+        size_t cnt = (size_t)blocks * 256 * 5;
+        std::vector<int32_t> h0(cnt), h1(cnt), h2(cnt), h3(cnt);
+        CHECK(hipMemcpy(h0.data(), o[0], cnt * 4, hipMemcpyDeviceToHost));
+        CHECK(hipMemcpy(h1.data(), o[1], cnt * 4, hipMemcpyDeviceToHost));
+        CHECK(hipMemcpy(h2.data(), o[2], cnt * 4, hipMemcpyDeviceToHost));
+        CHECK(hipMemcpy(h3.data(), o[3], cnt * 4, hipMemcpyDeviceToHost));
+        size_t bad1 = 0, bad2 = 0;
+        for (size_t i = 0; i < cnt; i++) { bad1 += h0[i] != h1[i]; bad2 += h3[i] != h2[i]; }
+        printf("asm(v) vs C++: %zu mismatches; asm(s) vs C++: %zu mismatches\n", bad1, bad2);
+        for (int k = 0; k < 4; k++) CHECK(hipFree(o[k]));
+        CHECK(hipFree(wt));
+        }
     }
     return 0;
 }
