@@ -25,6 +25,10 @@ for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
 
 LOG_N = 22
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak
+# HBM-side bytes per ntt_pass_kernel launch at 2^22, from the rocprofv3 PMC passes kept in
+# profiles/r01_ntt22_pmc_{fetch,write}.csv: mean over the three pass kernels of
+# 2 x FETCH_SIZE (gfx950 counts half of a wide read stream) + WRITE_SIZE.
+PMC_TRAFFIC_BYTES_PER_LAUNCH = (2 * 35840 + 65536) * 1024
 
 
 def _events_ms(torch, fn, reps):
@@ -139,7 +143,8 @@ def main():
             "config": {"workload": "single 2^22-point forward+inverse NTT per GPU, data resident in HBM",
                        "log_n": LOG_N, "elements_per_step": 2 * n, "parallelism": f"independent x{world}"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": PMC_TRAFFIC_BYTES_PER_LAUNCH,
+                         "algorithmic_bytes": int(alg_bytes),
                          "kernel": "ntt_pass_kernel (3 launches per transform)",
                          "avg_launch_us": round(avg_launch_ms * 1e3, 2)},
         }
