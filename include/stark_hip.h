@@ -95,6 +95,14 @@ int32_t stark_vec_mul(stark_ctx* ctx, const uint64_t* a, const uint64_t* b, uint
 int32_t stark_vec_mul_dev(stark_ctx* ctx, const uint64_t* a_dev, const uint64_t* b_dev, uint64_t* out_dev,
                           size_t n);
 
+/* Twiddle step of a four-step transform of n_total points split over devices
+ * (no counterpart in the single-threaded reference; the composition of the
+ * steps equals NTT::forward/inverse, ntt.rs:25-40): the row-major block
+ * data[i][k], i < n_rows, k < n_cols, is multiplied in place by
+ * w^((row_start + i) * k), w = primitive_nth_root(n_total) or its inverse. */
+int32_t stark_fourstep_twiddle_dev(stark_ctx* ctx, uint64_t* data_dev, size_t n_total, size_t row_start,
+                                   size_t n_rows, size_t n_cols, int32_t inverse);
+
 /* ---- Merkle ------------------------------------------------------------------
  * Merkle::commit (merkle.rs:38-51) over the leaves
  * bincode::serialize(&FieldElement) of n field elements (fri.rs:119,

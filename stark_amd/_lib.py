@@ -36,6 +36,7 @@ SIGNATURES = {
     "stark_ntt_batch_dev": (i32, [C.c_void_p, C.c_void_p, sz, sz, sz, i32]),
     "stark_coset_lde_batch": (i32, [C.c_void_p, C.c_void_p, sz, sz, sz, sz, u64p, C.c_void_p, sz]),
     "stark_coset_lde_batch_dev": (i32, [C.c_void_p, C.c_void_p, sz, sz, sz, sz, u64p, C.c_void_p, sz]),
+    "stark_fourstep_twiddle_dev": (i32, [C.c_void_p, C.c_void_p, sz, sz, sz, sz, i32]),
     "stark_vec_mul": (i32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, sz]),
     "stark_vec_mul_dev": (i32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, sz]),
     "stark_merkle_commit_fe": (i32, [C.c_void_p, C.c_void_p, sz, u8p, voidpp]),

@@ -647,6 +647,25 @@ extern "C" int32_t stark_vec_mul(stark_ctx* ctx, const uint64_t* a, const uint64
     return STARK_OK;
 }
 
+extern "C" int32_t stark_fourstep_twiddle_dev(stark_ctx* ctx, uint64_t* data_dev, size_t n_total, size_t row_start,
+                                              size_t n_rows, size_t n_cols, int32_t inverse)
+{
+    if (!ctx || (!data_dev && n_rows * n_cols)) return fail(STARK_EARG, "null argument");
+    int log_n;
+    ST_TRY(check_ntt_size(n_total, &log_n));
+    if (n_rows == 0 || n_cols == 0) return STARK_OK;
+    // the largest exponent (row_start + n_rows - 1) * (n_cols - 1) must stay below n_total
+    if ((row_start + n_rows - 1) * (n_cols - 1) >= n_total && n_cols > 1)
+        return fail(STARK_ELENGTH, "twiddle block exceeds the transform size");
+    fe w = ctx->F.primitive_nth_root((unsigned)log_n);
+    if (inverse) w = ctx->F.inverse(w);
+    const PowTables* pt;
+    ST_TRY(get_pow_tables(ctx, w, n_total, false, &pt));
+    HIP_TRY(launch_fourstep_twiddle((fe*)data_dev, row_start, n_rows, n_cols, (const fe*)pt->hi, (const fe*)pt->lo,
+                                    ctx->stream));
+    return STARK_OK;
+}
+
 // ===========================================================================
 // Merkle
 // ===========================================================================

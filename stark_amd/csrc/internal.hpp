@@ -63,6 +63,11 @@ struct SmallArgs {
 };
 hipError_t launch_ntt_small(const SmallArgs& a, uint32_t n_batch, hipStream_t s);
 
+// data[i][k] *= w^((row_start + i) * k) for an n_rows x n_cols row-major block;
+// hi/lo are the 16-byte power tables of w (lo[e] = w^e, e<256; hi[e] = w^(256 e)).
+hipError_t launch_fourstep_twiddle(fe* data, uint64_t row_start, uint64_t n_rows, uint64_t n_cols, const fe* hi,
+                                   const fe* lo, hipStream_t s);
+
 hipError_t launch_vec_mul(const fe* a, const fe* b, fe* out, size_t n, fe r2, hipStream_t s);
 
 // --- Merkle / FRI -----------------------------------------------------------

@@ -387,6 +387,36 @@ __global__ void vec_mul_kernel(const fe* __restrict__ x, const fe* __restrict__ 
     for (; i < n; i += step) out[i] = mont_mul(mont_mul(x[i], y[i]), r2);
 }
 
+// Twiddle step of a four-step transform split over devices: element (i, k) of a
+// row-major block is multiplied by w^((row_start + i) * k).
+__global__ void fourstep_twiddle_kernel(fe* __restrict__ data, uint64_t row_start, uint64_t n_rows, uint64_t n_cols,
+                                        const fe* __restrict__ hi, const fe* __restrict__ lo)
+{
+    const uint64_t total = n_rows * n_cols;
+    uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t step = (uint64_t)gridDim.x * blockDim.x;
+    for (; idx < total; idx += step) {
+        const uint64_t i = idx / n_cols, k = idx - i * n_cols;
+        const uint64_t E = (row_start + i) * k;
+        fe w = hi[E >> 8];
+        const uint32_t el = (uint32_t)(E & 255);
+        if (el) w = mont_mul(w, lo[el]);
+        data[idx] = mont_mul(data[idx], w);
+    }
+}
+
+hipError_t launch_fourstep_twiddle(fe* data, uint64_t row_start, uint64_t n_rows, uint64_t n_cols, const fe* hi,
+                                   const fe* lo, hipStream_t s)
+{
+    const uint64_t total = n_rows * n_cols;
+    if (total == 0) return hipSuccess;
+    uint64_t blocks = (total + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(fourstep_twiddle_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, data, row_start, n_rows, n_cols,
+                       hi, lo);
+    return hipGetLastError();
+}
+
 hipError_t launch_vec_mul(const fe* a, const fe* b, fe* out, size_t n, fe r2, hipStream_t s)
 {
     if (n == 0) return hipSuccess;

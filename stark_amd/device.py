@@ -186,6 +186,11 @@ class Context:
         self._chk(self.lib.stark_coset_lde_batch_dev(self.h, _ptr(coeffs_ptr), n_coeffs, coeff_stride, n_cols,
                                                      n_out, _fe(offset), _ptr(out_ptr), out_stride))
 
+    def fourstep_twiddle_dev(self, dptr, n_total: int, row_start: int, n_rows: int, n_cols: int,
+                             inverse: bool = False):
+        self._chk(self.lib.stark_fourstep_twiddle_dev(self.h, _ptr(dptr), n_total, row_start, n_rows, n_cols,
+                                                      int(inverse)))
+
     def vec_mul(self, a, b) -> np.ndarray:
         a, b = _as_fe_array(a), _as_fe_array(b)
         assert a.shape == b.shape
