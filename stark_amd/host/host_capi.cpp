@@ -1,0 +1,281 @@
+// C shims over the C++ host mirror (stark_host.hpp) so that the Python test
+// suite can drive it.  Test plumbing only: a Rust or C++ caller uses the
+// mirror / the C ABI directly.  Every function that can raise stark::Panic
+// returns -1 and stores the message for sh_last_panic().
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+#include "stark_host.hpp"
+
+using namespace stark;
+
+static thread_local std::string g_panic;
+
+#define GUARD(...)                        \
+    try {                                 \
+        __VA_ARGS__                       \
+    } catch (const std::exception& e) {   \
+        g_panic = e.what();               \
+        return -1;                        \
+    }
+
+static FieldElement ld(const uint64_t* p) { return FieldElement{((u128)p[1] << 64) | p[0]}; }
+static void st(uint64_t* p, const FieldElement& x)
+{
+    p[0] = (uint64_t)x.value;
+    p[1] = (uint64_t)(x.value >> 64);
+}
+static std::vector<FieldElement> ldv(const uint64_t* p, size_t n)
+{
+    std::vector<FieldElement> v(n);
+    for (size_t i = 0; i < n; i++) v[i] = ld(p + 2 * i);
+    return v;
+}
+static void stv(uint64_t* p, const std::vector<FieldElement>& v)
+{
+    for (size_t i = 0; i < v.size(); i++) st(p + 2 * i, v[i]);
+}
+static std::vector<std::vector<uint8_t>> leaves_of(const uint8_t* flat, const uint64_t* offs, size_t n)
+{
+    std::vector<std::vector<uint8_t>> out(n);
+    for (size_t i = 0; i < n; i++) out[i].assign(flat + offs[i], flat + offs[i + 1]);
+    return out;
+}
+
+extern "C" {
+
+const char* sh_last_panic() { return g_panic.c_str(); }
+
+// ---- field.rs ---------------------------------------------------------------
+int sh_fe_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* out)
+{
+    GUARD(
+        FieldElement x = ld(a), y = b ? ld(b) : FieldElement::zero(), r;
+        switch (op) {
+        case 0: r = x + y; break;
+        case 1: r = x - y; break;
+        case 2: r = x * y; break;
+        case 3: r = x / y; break;
+        case 4: r = -x; break;
+        case 5: r = x.inverse(); break;
+        default: throw Panic("bad op");
+        }
+        st(out, r);
+        return 0;)
+}
+int sh_fe_pow(const uint64_t* a, const uint64_t* e, uint64_t* out)
+{
+    GUARD(st(out, ld(a).pow(((u128)e[1] << 64) | e[0])); return 0;)
+}
+int sh_primitive_nth_root(const uint64_t* n, uint64_t* out)
+{
+    GUARD(st(out, FieldElement::primitive_nth_root(((u128)n[1] << 64) | n[0])); return 0;)
+}
+int sh_fe_sample(const uint8_t* bytes, size_t len, uint64_t* out)
+{
+    GUARD(st(out, FieldElement::sample(std::vector<uint8_t>(bytes, bytes + len))); return 0;)
+}
+size_t sh_fe_to_string(const uint64_t* a, char* buf)
+{
+    std::string s = ld(a).to_string();
+    std::memcpy(buf, s.data(), s.size());
+    return s.size();
+}
+size_t sh_bincode_fe(const uint64_t* a, uint8_t* buf)
+{
+    std::vector<uint8_t> b = wire::bincode_field_element(ld(a));
+    std::memcpy(buf, b.data(), b.size());
+    return b.size();
+}
+
+// ---- hashes -------------------------------------------------------------------
+void sh_blake2b(const uint8_t* in, size_t len, uint8_t* out, size_t outlen)
+{
+    std::vector<uint8_t> d = hash::blake2b(in, len, outlen);
+    std::memcpy(out, d.data(), outlen);
+}
+void sh_shake256(const uint8_t* in, size_t len, uint8_t* out, size_t outlen)
+{
+    std::vector<uint8_t> d = hash::shake256(in, len, outlen);
+    std::memcpy(out, d.data(), outlen);
+}
+
+// ---- proof_stream.rs -------------------------------------------------------------
+void* sh_ps_new() { return new ProofStream(); }
+void sh_ps_free(void* ps) { delete static_cast<ProofStream*>(ps); }
+void sh_ps_push(void* ps, const char* s, size_t len) { static_cast<ProofStream*>(ps)->push(std::string(s, len)); }
+int sh_ps_pull(void* ps, char* buf, size_t* len)
+{
+    GUARD(
+        std::string s = static_cast<ProofStream*>(ps)->pull();
+        if (buf) std::memcpy(buf, s.data(), s.size());
+        *len = s.size();
+        return 0;)
+}
+size_t sh_ps_count(void* ps) { return static_cast<ProofStream*>(ps)->objects.size(); }
+size_t sh_ps_object(void* ps, size_t i, char* buf)
+{
+    const std::string& s = static_cast<ProofStream*>(ps)->objects[i];
+    if (buf) std::memcpy(buf, s.data(), s.size());
+    return s.size();
+}
+size_t sh_ps_serialize(void* ps, uint8_t* buf)
+{
+    std::vector<uint8_t> b = static_cast<ProofStream*>(ps)->serialize();
+    if (buf) std::memcpy(buf, b.data(), b.size());
+    return b.size();
+}
+void* sh_ps_deserialize(const uint8_t* bytes, size_t len)
+{
+    try {
+        return new ProofStream(ProofStream::deserialize(std::vector<uint8_t>(bytes, bytes + len)));
+    } catch (const std::exception& e) {
+        g_panic = e.what();
+        return nullptr;
+    }
+}
+void sh_ps_fiat_shamir(void* ps, int verifier, uint8_t* out, size_t nbytes)
+{
+    ProofStream* p = static_cast<ProofStream*>(ps);
+    std::vector<uint8_t> d = verifier ? p->verifier_fiat_shamir(nbytes) : p->prover_fiat_shamir(nbytes);
+    std::memcpy(out, d.data(), nbytes);
+}
+
+// ---- ntt.rs / univariate_poly.rs (device) ------------------------------------------
+int sh_ntt(uint64_t* data, size_t len, size_t n, int inverse)
+{
+    GUARD(
+        NTT ntt(n);
+        std::vector<FieldElement> v = ldv(data, len);
+        if (inverse) ntt.inverse(v); else ntt.forward(v);
+        stv(data, v);
+        return 0;)
+}
+int sh_ntt_evaluate(const uint64_t* coeffs, size_t n_coeffs, size_t n, uint64_t* out)
+{
+    GUARD(stv(out, NTT(n).evaluate(ldv(coeffs, n_coeffs))); return 0;)
+}
+int sh_ntt_multiply(const uint64_t* a, size_t na, const uint64_t* b, size_t nb, uint64_t* out)
+{
+    GUARD(stv(out, NTT(8).multiply(ldv(a, na), ldv(b, nb))); return 0;)
+}
+int sh_eval_domain(const uint64_t* coeffs_high_first, size_t n_coeffs, const uint64_t* domain, size_t n, uint64_t* out)
+{
+    GUARD(
+        Polynomial p{ldv(coeffs_high_first, n_coeffs)};
+        stv(out, p.eval_domain(ldv(domain, n)));
+        return 0;)
+}
+int sh_lagrange(const uint64_t* x, const uint64_t* y, size_t n, uint64_t* out, size_t* out_len)
+{
+    GUARD(
+        Polynomial p = Polynomial::lagrange(ldv(x, n), ldv(y, n));
+        stv(out, p.coeffs);
+        *out_len = p.coeffs.size();
+        return 0;)
+}
+
+// ---- merkle.rs ---------------------------------------------------------------------
+int sh_merkle_commit(const uint8_t* flat, const uint64_t* offs, size_t n, uint8_t* root)
+{
+    GUARD(HashOutput r = Merkle::commit(leaves_of(flat, offs, n)); std::memcpy(root, r.data(), 32); return 0;)
+}
+int sh_merkle_open(size_t index, const uint8_t* flat, const uint64_t* offs, size_t n, uint8_t* path, size_t* depth)
+{
+    GUARD(
+        std::vector<HashOutput> p = Merkle::open(index, leaves_of(flat, offs, n));
+        for (size_t k = 0; k < p.size(); k++) std::memcpy(path + 32 * k, p[k].data(), 32);
+        *depth = p.size();
+        return 0;)
+}
+int sh_merkle_verify(const uint8_t* root, size_t index, const uint8_t* path, size_t depth, const uint8_t* leaf,
+                     size_t leaf_len)
+{
+    GUARD(
+        HashOutput r;
+        std::memcpy(r.data(), root, 32);
+        std::vector<HashOutput> p(depth);
+        for (size_t k = 0; k < depth; k++) std::memcpy(p[k].data(), path + 32 * k, 32);
+        return Merkle::verify(r, index, p, std::vector<uint8_t>(leaf, leaf + leaf_len)) ? 1 : 0;)
+}
+int sh_merkle_commit_host(const uint8_t* flat, const uint64_t* offs, size_t n, uint8_t* root)
+{
+    GUARD(HashOutput r = Merkle::commit_host(leaves_of(flat, offs, n)); std::memcpy(root, r.data(), 32); return 0;)
+}
+
+// ---- fri.rs ----------------------------------------------------------------------------
+static Fri make_fri(const uint64_t* offset, const uint64_t* omega, size_t n, size_t expansion, size_t ncol)
+{
+    return Fri(ld(offset), ld(omega), n, expansion, ncol);
+}
+int sh_fri_num_rounds(const uint64_t* offset, const uint64_t* omega, size_t n, size_t expansion, size_t ncol)
+{
+    GUARD(return (int)make_fri(offset, omega, n, expansion, ncol).num_rounds();)
+}
+int sh_fri_sample_indices(const uint8_t* seed, size_t seed_len, size_t size, size_t reduced, size_t number,
+                          uint64_t* out)
+{
+    GUARD(
+        uint64_t one[2] = {1, 0};
+        Fri f = make_fri(one, one, 1 << 20, 4, 1);
+        std::vector<size_t> idx = f.sample_indices(std::vector<uint8_t>(seed, seed + seed_len), size, reduced, number);
+        for (size_t i = 0; i < idx.size(); i++) out[i] = idx[i];
+        return 0;)
+}
+// layers_out: all codewords concatenated (may be NULL); returns the number of layers
+int sh_fri_commit(const uint64_t* cw, size_t n, const uint64_t* offset, const uint64_t* omega, size_t expansion,
+                  size_t ncol, void* ps, uint64_t* layers_out)
+{
+    GUARD(
+        Fri f = make_fri(offset, omega, n, expansion, ncol);
+        std::vector<std::vector<FieldElement>> layers = f.commit(ldv(cw, n), *static_cast<ProofStream*>(ps));
+        size_t off = 0;
+        if (layers_out)
+            for (auto& l : layers) { stv(layers_out + 2 * off, l); off += l.size(); }
+        return (int)layers.size();)
+}
+int sh_fri_prove(const uint64_t* cw, size_t n, const uint64_t* offset, const uint64_t* omega, size_t expansion,
+                 size_t ncol, void* ps, uint64_t* indices_out)
+{
+    GUARD(
+        Fri f = make_fri(offset, omega, n, expansion, ncol);
+        std::vector<size_t> idx = f.prove(ldv(cw, n), *static_cast<ProofStream*>(ps));
+        for (size_t i = 0; i < idx.size(); i++) indices_out[i] = idx[i];
+        return (int)idx.size();)
+}
+// prove through the reference-shaped commit() + query() (codewords by value, trees rebuilt)
+int sh_fri_prove_by_value(const uint64_t* cw, size_t n, const uint64_t* offset, const uint64_t* omega,
+                          size_t expansion, size_t ncol, void* psv)
+{
+    GUARD(
+        Fri f = make_fri(offset, omega, n, expansion, ncol);
+        ProofStream& ps = *static_cast<ProofStream*>(psv);
+        std::vector<std::vector<FieldElement>> cws = f.commit(ldv(cw, n), ps);
+        std::vector<size_t> top = f.sample_indices(ps.prover_fiat_shamir(32), cws[0].size() / 2, cws.back().size(), ncol);
+        std::vector<size_t> indices = top;
+        for (size_t i = 0; i + 1 < cws.size(); i++) {
+            for (size_t& idx : indices) idx %= cws[i].size() / 2;
+            indices = f.query(cws[i], cws[i + 1], indices, ps);
+        }
+        return 0;)
+}
+// returns 1 (accept) / 0 (reject) / -1 (panic); points as (index, value) pairs
+int sh_fri_verify(const uint64_t* offset, const uint64_t* omega, size_t n, size_t expansion, size_t ncol, void* ps,
+                  uint64_t* point_idx, uint64_t* point_val, size_t* n_points)
+{
+    GUARD(
+        Fri f = make_fri(offset, omega, n, expansion, ncol);
+        std::vector<std::pair<size_t, FieldElement>> pts;
+        bool ok = f.verify(*static_cast<ProofStream*>(ps), pts);
+        if (n_points) {
+            for (size_t i = 0; i < pts.size(); i++) {
+                if (point_idx) point_idx[i] = pts[i].first;
+                if (point_val) st(point_val + 2 * i, pts[i].second);
+            }
+            *n_points = pts.size();
+        }
+        return ok ? 1 : 0;)
+}
+
+}  // extern "C"
