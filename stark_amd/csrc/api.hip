@@ -79,6 +79,7 @@ struct stark_ctx {
     size_t scratch_elems = 0;
     std::multimap<size_t, void*> pool;                 // cached device blocks by size
     void* pinned = nullptr;                            // small pinned staging buffer (4 KiB)
+    fe* zero_block = nullptr;                          // 64 zero bytes on the device
 };
 
 struct stark_tree {
@@ -332,6 +333,7 @@ static int32_t run_ntt(stark_ctx* ctx, const fe* src, size_t src_stride, size_t 
             a.hi = t->hi;
             a.lo = t->lo;
             a.fin = t->fin;
+            a.zero_block = ctx->zero_block;
             a.log_n = log_n;
             a.log_s = log_s;
             a.log_s_next = (q + 1 < P) ? log_s - t->radices[q + 1] : 0;
@@ -444,6 +446,8 @@ extern "C" int32_t stark_ctx_create(int32_t device, stark_ctx** out)
     ctx->device = device;
     hipError_t e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipHostMalloc(&ctx->pinned, 4096, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMalloc((void**)&ctx->zero_block, 64);
+    if (e == hipSuccess) e = hipMemset(ctx->zero_block, 0, 64);
     if (e != hipSuccess) {
         delete ctx;
         return fail(STARK_EHIP, std::string("stark_ctx_create: ") + hipGetErrorString(e));
@@ -467,6 +471,7 @@ extern "C" void stark_ctx_destroy(stark_ctx* ctx)
     for (auto& kv : ctx->pool) (void)hipFree(kv.second);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->zero_block) (void)hipFree(ctx->zero_block);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }

@@ -32,6 +32,7 @@ struct PassArgs {
     const tw5* fin;        // 1 (forward) or n^-1 (inverse): multiplier of the last pass's outputs
     const tw5* twist_hi;   // s^(256 i), first pass of a coset transform
     const tw5* twist_lo;   // s^i, i<256
+    const fe* zero_block;  // 16 zero bytes in device memory (padding source of the asynchronous copy)
     uint64_t src_batch_stride;   // elements between consecutive transforms of a batch
     uint64_t dst_batch_stride;
     uint64_t n_src;        // valid source elements (first pass zero-fills the rest)

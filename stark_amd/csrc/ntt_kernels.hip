@@ -13,6 +13,8 @@
 // coefficients of the first pass, and the padding zeros are never read.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "field5.hpp"
 #include "internal.hpp"
 
@@ -155,140 +157,260 @@ __device__ __forceinline__ void load_tile(fe (&raw)[16], const PassArgs& a, uint
     }
 }
 
+// Geometry of one pass kernel instantiation.
+template <int RA, int MODE>
+struct Geo {
+    static constexpr int M1 = 1 << RA;          // round-1 radix
+    static constexpr int G1 = 16 / M1;          // round-1 groups per thread
+    static constexpr int R = 16 * M1;           // sub-transform size of this pass
+    static constexpr int LOGC = 8 - RA;
+    static constexpr int C = 1 << LOGC;         // columns (rows in PASS_LAST) per tile
+    static constexpr int PITCH = (MODE == PASS_LAST) ? (C + 1) : C;
+    static constexpr int TWSHIFT = 8 - (RA + 4);
+    static constexpr int LDS_ELEMS = R * PITCH; // >= 4096: also the staging area of the prefetch
+};
+
+// canonical loads -> lazy limbs, plus the coset twist of a first pass
+template <int RA, int MODE, bool TWIST>
+__device__ __forceinline__ void unpack_tile(fe5 (&v)[16], const fe (&raw)[16], const PassArgs& a, uint32_t tx, int t)
+{
+    using G = Geo<RA, MODE>;
+#pragma unroll
+    for (int i = 0; i < 16; i++) v[i] = unpack5(raw[i]);
+    if constexpr (MODE == PASS_FIRST && TWIST) {
+#pragma unroll
+        for (int g = 0; g < G::G1; g++) {
+            const int q1 = t + TILE_THREADS * g;
+            const int jb = q1 >> G::LOGC, c = q1 & (G::C - 1);
+            const uint64_t f = (uint64_t)tx * G::C + c;
+            const uint64_t pre = f >> a.log_s;
+            const uint64_t col = f & (((uint64_t)1 << a.log_s) - 1);
+            const uint64_t base = (pre << (a.r + a.log_s)) + col;
+#pragma unroll
+            for (int ja = 0; ja < G::M1; ja++) {
+                const uint64_t idx = base + ((uint64_t)(ja * 16 + jb) << a.log_s);
+                if (idx < a.n_src)
+                    v[g * G::M1 + ja] = mont_mul5_v(
+                        v[g * G::M1 + ja], mont_mul5_v(*(const fe5*)&a.twist_hi[idx >> 8], a.twist_lo[idx & 255]));
+            }
+        }
+    }
+}
+
+// round 1 (radix M1 over ja), inner twiddle w_R^(jb*ka), exchange through LDS;
+// on return v holds the 16 round-2 inputs of this thread.  Ends with every
+// thread's LDS reads issued and waited for, but NOT with a barrier.
+template <int RA, int MODE>
+__device__ __forceinline__ void round1_exchange(fe5 (&v)[16], fe* lds, const tw5* s_tw256, const tw5* __restrict__ tw16,
+                                                int t)
+{
+    using G = Geo<RA, MODE>;
+    RoundOne<RA, G::G1>::run(v, tw16);
+#pragma unroll
+    for (int g = 0; g < G::G1; g++) {
+        const int q1 = t + TILE_THREADS * g;
+        int jb, c;
+        if constexpr (MODE == PASS_LAST) { c = q1 >> 4; jb = q1 & 15; }
+        else { jb = q1 >> G::LOGC; c = q1 & (G::C - 1); }
+#pragma unroll
+        for (int ka = 0; ka < G::M1; ka++) {
+            const int reg = g * G::M1 + brev_c(ka, RA);
+            const fe5 x = mont_mul5_v(v[reg], s_tw256[(jb * ka) << G::TWSHIFT]);
+            lds[(ka * 16 + jb) * G::PITCH + c] = finish(x);
+        }
+    }
+    lds_barrier();
+    const int ka2 = t >> G::LOGC, c2 = t & (G::C - 1);
+#pragma unroll
+    for (int jb = 0; jb < 16; jb++) v[jb] = unpack5(lds[(ka2 * 16 + jb) * G::PITCH + c2]);
+}
+
+// round 2 (radix 16 over jb), outgoing twiddle, store
+template <int RA, int MODE, bool NEXT_LAST>
+__device__ __forceinline__ void round2_store(fe5 (&v)[16], const PassArgs& a, fe* __restrict__ dst, uint32_t tx,
+                                             const tw5* __restrict__ tw16, int t)
+{
+    using G = Geo<RA, MODE>;
+    constexpr int M1 = G::M1;
+    const int ka2 = t >> G::LOGC, c2 = t & (G::C - 1);
+    ntt_dif_reg<4, 0>(v, tw16);
+    if constexpr (MODE == PASS_LAST) {
+        const uint64_t b = (uint64_t)tx * G::C + c2;
+        const uint32_t sh = a.log_n - a.r;
+        const tw5 fin = *a.fin;
+#pragma unroll
+        for (int kb = 0; kb < 16; kb++) {
+            const uint64_t k = ka2 + M1 * kb;
+            dst[(k << sh) + b] = finish(mont_mul5_s(v[brev_c(kb, 4)], fin));
+        }
+    } else {
+        const uint64_t f = (uint64_t)tx * G::C + c2;
+        const uint32_t pre = (uint32_t)(f >> a.log_s);
+        const uint64_t col = f & (((uint64_t)1 << a.log_s) - 1);
+        const uint64_t base = ((uint64_t)pre << (a.r + a.log_s)) + col;
+        // twiddle of the next pass: w_n^(j_next * K * S_next), K = K_prev + k * 2^bits_prev
+        const uint32_t j_next = (uint32_t)(col >> a.log_s_next);
+        uint32_t bits_prev = 0;
+        for (uint32_t u = 0; u < a.nprev; u++) bits_prev += a.rprev[u];
+        const uint32_t k_prev = prefix_to_k(pre, a);
+        if constexpr (NEXT_LAST) {
+            // S_next = 1: exponent j_next * K, split over the hi and lo tables
+#pragma clang loop unroll(full)
+            for (int kb = 0; kb < 16; kb++) {
+                const uint32_t k = ka2 + M1 * kb;
+                const uint32_t E = j_next * (k_prev + (k << bits_prev));
+                const fe5 w = mont_mul5_v(*(const fe5*)&a.hi[E >> a.h], a.lo[E & ((1u << a.h) - 1)]);
+                dst[base + ((uint64_t)k << a.log_s)] = finish(mont_mul5_v(v[brev_c(kb, 4)], w));
+            }
+        } else {
+            const uint32_t sn = a.log_s_next - a.h;                // S_next / 2^h
+#pragma clang loop unroll(full)
+            for (int kb = 0; kb < 16; kb++) {
+                const uint32_t k = ka2 + M1 * kb;
+                const uint32_t E = (j_next * (k_prev + (k << bits_prev))) << sn;
+                dst[base + ((uint64_t)k << a.log_s)] = finish(mont_mul5_v(v[brev_c(kb, 4)], a.hi[E]));
+            }
+        }
+    }
+}
+
 // RA = log2(R) - 4.  MODE: PASS_FIRST (strided columns, optional coset twist,
 // zero fill), PASS_MIDDLE (strided columns), PASS_LAST (contiguous rows,
 // transposed store to natural order).  The twiddle that the NEXT pass needs is
 // applied to this pass's outputs, so every element leaves the pass through a
 // multiplication, which is what brings the lazy limbs back to a canonical
 // value; the last pass multiplies by `fin` (1, or n^-1 for the inverse).
-// One workgroup per tile: two workgroups are resident per CU (LDS- and
-// register-limited), and it is the second one that hides the first one's
-// global-memory latency.  (A persistent loop that prefetched the next tile into
-// registers was measured slower: the extra 64 registers spill, and a spill
-// reload's vmcnt wait drains the prefetch.)
+// One workgroup per tile; the second resident workgroup of the CU hides this
+// one's global-memory latency.
 template <int RA, int MODE, bool TWIST, bool NEXT_LAST>
 __global__ __launch_bounds__(TILE_THREADS) void ntt_pass_kernel(PassArgs a, uint64_t total_tiles)
 {
-    constexpr int M1 = 1 << RA;          // round-1 radix
-    constexpr int G1 = 16 / M1;          // round-1 groups per thread
-    constexpr int R = 16 * M1;           // sub-transform size of this pass
-    constexpr int LOGC = 8 - RA;
-    constexpr int C = 1 << LOGC;         // columns (rows in PASS_LAST) per tile
-    constexpr int PITCH = (MODE == PASS_LAST) ? (C + 1) : C;
-    constexpr int TWSHIFT = 8 - (RA + 4);
-
-    __shared__ fe lds[R * PITCH];
+    using G = Geo<RA, MODE>;
+    __shared__ fe lds[G::LDS_ELEMS];
     __shared__ tw5 s_tw256[256];
-
     const int t = threadIdx.x;
     const tw5* __restrict__ tw16 = a.tw16;
     const uint32_t ltiles = a.log_n - 12;
-
     s_tw256[t] = a.tw256[t];
-
-    fe raw[16];
-    fe5 v[16];
-
-    const uint64_t tile = blockIdx.x;
-    load_tile<RA, MODE>(raw, a, tile, t);
     (void)total_tiles;
 
-    {
-        const uint64_t batch = tile >> ltiles;
-        const uint32_t tx = (uint32_t)(tile & (((uint64_t)1 << ltiles) - 1));
-        fe* __restrict__ dst = a.dst + batch * a.dst_batch_stride;
+    const uint64_t tile = blockIdx.x;
+    const uint64_t batch = tile >> ltiles;
+    const uint32_t tx = (uint32_t)(tile & (((uint64_t)1 << ltiles) - 1));
+    fe raw[16];
+    fe5 v[16];
+    load_tile<RA, MODE>(raw, a, tile, t);
+    unpack_tile<RA, MODE, TWIST>(v, raw, a, tx, t);
+    lds_barrier();          // s_tw256 staged
+    round1_exchange<RA, MODE>(v, lds, s_tw256, tw16, t);
+    round2_store<RA, MODE, NEXT_LAST>(v, a, a.dst + batch * a.dst_batch_stride, tx, tw16, t);
+}
 
-        // ---- unpack (and coset twist) ----------------------------------------------
+// Asynchronous copy of one tile's 16 loads per thread straight into LDS
+// (global_load_lds: no destination registers).  Slot i of thread t lands at
+// stage[i*256 + t]; a wave's 64 lanes write 1 KiB contiguously, as the
+// instruction requires.  Zero padding of a first pass reads a zero block.
+template <int RA, int MODE>
+__device__ __forceinline__ void prefetch_tile(fe* stage, const PassArgs& a, uint64_t tile, int t)
+{
+    using G = Geo<RA, MODE>;
+    const uint32_t ltiles = a.log_n - 12;
+    const uint64_t batch = tile >> ltiles;
+    const uint32_t tx = (uint32_t)(tile & (((uint64_t)1 << ltiles) - 1));
+    const fe* __restrict__ src = a.src + batch * a.src_batch_stride;
+    const int wave_base = t & ~63;
 #pragma unroll
-        for (int i = 0; i < 16; i++) v[i] = unpack5(raw[i]);
-        if constexpr (MODE == PASS_FIRST && TWIST) {
-#pragma unroll
-            for (int g = 0; g < G1; g++) {
-                const int q1 = t + TILE_THREADS * g;
-                const int jb = q1 >> LOGC, c = q1 & (C - 1);
-                const uint64_t f = (uint64_t)tx * C + c;
-                const uint64_t pre = f >> a.log_s;
-                const uint64_t col = f & (((uint64_t)1 << a.log_s) - 1);
-                const uint64_t base = (pre << (a.r + a.log_s)) + col;
-#pragma unroll
-                for (int ja = 0; ja < M1; ja++) {
-                    const uint64_t idx = base + ((uint64_t)(ja * 16 + jb) << a.log_s);
-                    if (idx < a.n_src)
-                        v[g * M1 + ja] = mont_mul5_v(
-                            v[g * M1 + ja], mont_mul5_v(*(const fe5*)&a.twist_hi[idx >> 8], a.twist_lo[idx & 255]));
-                }
-            }
-        }
-
-        lds_barrier();          // s_tw256 staged
-
-        // ---- round 1: radix M1 over ja ---------------------------------------------
-        RoundOne<RA, G1>::run(v, tw16);
-
-        // ---- inner twiddle w_R^(jb*ka), exchange through LDS -----------------------
-#pragma unroll
-        for (int g = 0; g < G1; g++) {
-            const int q1 = t + TILE_THREADS * g;
-            int jb, c;
-            if constexpr (MODE == PASS_LAST) { c = q1 >> 4; jb = q1 & 15; }
-            else { jb = q1 >> LOGC; c = q1 & (C - 1); }
-#pragma unroll
-            for (int ka = 0; ka < M1; ka++) {
-                const int reg = g * M1 + brev_c(ka, RA);
-                const fe5 x = mont_mul5_v(v[reg], s_tw256[(jb * ka) << TWSHIFT]);
-                lds[(ka * 16 + jb) * PITCH + c] = finish(x);
-            }
-        }
-
-        lds_barrier();
-
-        // ---- round 2: radix 16 over jb ----------------------------------------------
-        const int ka2 = t >> LOGC, c2 = t & (C - 1);
-#pragma unroll
-        for (int jb = 0; jb < 16; jb++) v[jb] = unpack5(lds[(ka2 * 16 + jb) * PITCH + c2]);
-
-        ntt_dif_reg<4, 0>(v, tw16);
-
-        // ---- outgoing twiddle + store ------------------------------------------------
+    for (int g = 0; g < G::G1; g++) {
+        const int q1 = t + TILE_THREADS * g;
         if constexpr (MODE == PASS_LAST) {
-            const uint64_t b = (uint64_t)tx * C + c2;
-            const uint32_t sh = a.log_n - a.r;
-            const tw5 fin = *a.fin;
+            const int c = q1 >> 4, jb = q1 & 15;
+            const uint32_t b = tx * G::C + c;
+            const uint64_t row = (uint64_t)k_to_prefix(b, a) << a.r;
 #pragma unroll
-            for (int kb = 0; kb < 16; kb++) {
-                const uint64_t k = ka2 + M1 * kb;
-                dst[(k << sh) + b] = finish(mont_mul5_s(v[brev_c(kb, 4)], fin));
+            for (int ja = 0; ja < G::M1; ja++) {
+                const fe* gp = src + row + ja * 16 + jb;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
+                                                 (__attribute__((address_space(3))) void*)&stage[(g * G::M1 + ja) * 256 + wave_base],
+                                                 16, 0, 0);
             }
         } else {
-            const uint64_t f = (uint64_t)tx * C + c2;
-            const uint32_t pre = (uint32_t)(f >> a.log_s);
+            const int jb = q1 >> G::LOGC, c = q1 & (G::C - 1);
+            const uint64_t f = (uint64_t)tx * G::C + c;
+            const uint64_t pre = f >> a.log_s;
             const uint64_t col = f & (((uint64_t)1 << a.log_s) - 1);
-            const uint64_t base = ((uint64_t)pre << (a.r + a.log_s)) + col;
-            // twiddle of the next pass: w_n^(j_next * K * S_next), K = K_prev + k * 2^bits_prev
-            const uint32_t j_next = (uint32_t)(col >> a.log_s_next);
-            uint32_t bits_prev = 0;
-            for (uint32_t u = 0; u < a.nprev; u++) bits_prev += a.rprev[u];
-            const uint32_t k_prev = prefix_to_k(pre, a);
-            if constexpr (NEXT_LAST) {
-                // S_next = 1: exponent j_next * K, split over the hi and lo tables
-#pragma clang loop unroll(full)
-                for (int kb = 0; kb < 16; kb++) {
-                    const uint32_t k = ka2 + M1 * kb;
-                    const uint32_t E = j_next * (k_prev + (k << bits_prev));
-                    const fe5 w = mont_mul5_v(*(const fe5*)&a.hi[E >> a.h], a.lo[E & ((1u << a.h) - 1)]);
-                    dst[base + ((uint64_t)k << a.log_s)] = finish(mont_mul5_v(v[brev_c(kb, 4)], w));
+            const uint64_t base = (pre << (a.r + a.log_s)) + col;
+#pragma unroll
+            for (int ja = 0; ja < G::M1; ja++) {
+                const uint64_t idx = base + ((uint64_t)(ja * 16 + jb) << a.log_s);
+                const fe* gp = src + idx;
+                if constexpr (MODE == PASS_FIRST) {
+                    if (idx >= a.n_src) gp = a.zero_block;
                 }
-            } else {
-                const uint32_t sn = a.log_s_next - a.h;                // S_next / 2^h
-#pragma clang loop unroll(full)
-                for (int kb = 0; kb < 16; kb++) {
-                    const uint32_t k = ka2 + M1 * kb;
-                    const uint32_t E = (j_next * (k_prev + (k << bits_prev))) << sn;
-                    dst[base + ((uint64_t)k << a.log_s)] = finish(mont_mul5_v(v[brev_c(kb, 4)], a.hi[E]));
-                }
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
+                                                 (__attribute__((address_space(3))) void*)&stage[(g * G::M1 + ja) * 256 + wave_base],
+                                                 16, 0, 0);
             }
         }
     }
+}
+
+// Persistent form: a workgroup walks tiles blockIdx.x, +gridDim.x, ... and
+// copies its NEXT tile into LDS asynchronously while it computes round 2 of
+// the current one.  The copy reuses the exchange buffer, which is idle from
+// the end of the round-2 reads until the next tile's round-1 writes, so
+// neither LDS nor registers grow and two workgroups stay resident per CU.
+template <int RA, int MODE, bool TWIST, bool NEXT_LAST>
+__global__ __launch_bounds__(TILE_THREADS) void ntt_pass_kernel_persist(PassArgs a, uint64_t total_tiles)
+{
+    using G = Geo<RA, MODE>;
+    __shared__ fe lds[G::LDS_ELEMS];
+    __shared__ tw5 s_tw256[256];
+    const int t = threadIdx.x;
+    const tw5* __restrict__ tw16 = a.tw16;
+    const uint32_t ltiles = a.log_n - 12;
+    s_tw256[t] = a.tw256[t];
+
+    uint64_t tile = blockIdx.x;
+    if (tile < total_tiles) prefetch_tile<RA, MODE>(lds, a, tile, t);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (; tile < total_tiles; tile += gridDim.x) {
+        const uint64_t batch = tile >> ltiles;
+        const uint32_t tx = (uint32_t)(tile & (((uint64_t)1 << ltiles) - 1));
+        fe raw[16];
+        fe5 v[16];
+        // this thread's own 16 slots (written by its own wave's copy instructions)
+#pragma unroll
+        for (int i = 0; i < 16; i++) raw[i] = lds[i * 256 + t];
+        unpack_tile<RA, MODE, TWIST>(v, raw, a, tx, t);
+        lds_barrier();      // staging area fully read (and s_tw256 staged) before the exchange overwrites it
+        round1_exchange<RA, MODE>(v, lds, s_tw256, tw16, t);
+        lds_barrier();      // exchange buffer fully read before the next copy lands in it
+        const bool more = tile + gridDim.x < total_tiles;
+        if (more) prefetch_tile<RA, MODE>(lds, a, tile + gridDim.x, t);
+        round2_store<RA, MODE, NEXT_LAST>(v, a, a.dst + batch * a.dst_batch_stride, tx, tw16, t);
+        // The copy is older than this tile's 16 stores and every table load has been consumed,
+        // so "all but the 16 youngest" means the copy has landed.
+        if (more) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    }
+}
+
+static uint32_t persistent_grid()
+{
+    static uint32_t cached = [] {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        return (uint32_t)(cus > 0 ? cus : 256) * 2;      // two resident workgroups per CU
+    }();
+    return cached;
+}
+
+static bool use_persistent()
+{
+    static const bool on = [] {
+        const char* e = getenv("STARK_NTT_PERSIST");
+        return e && e[0] == '1';
+    }();
+    return on;
 }
 
 template <int RA, int MODE, bool TWIST, bool NEXT_LAST>
@@ -296,8 +418,13 @@ static hipError_t launch_one(const PassArgs& a, uint32_t n_batch, hipStream_t s)
 {
     const uint64_t total = (((uint64_t)1 << a.log_n) / TILE_ELEMS) * n_batch;
     if (total > 0x7fffffffull) return hipErrorInvalidValue;
-    const uint32_t grid = (uint32_t)total;
-    hipLaunchKernelGGL((ntt_pass_kernel<RA, MODE, TWIST, NEXT_LAST>), dim3(grid), dim3(TILE_THREADS), 0, s, a, total);
+    if (use_persistent() && total > persistent_grid()) {
+        hipLaunchKernelGGL((ntt_pass_kernel_persist<RA, MODE, TWIST, NEXT_LAST>), dim3(persistent_grid()),
+                           dim3(TILE_THREADS), 0, s, a, total);
+    } else {
+        hipLaunchKernelGGL((ntt_pass_kernel<RA, MODE, TWIST, NEXT_LAST>), dim3((uint32_t)total), dim3(TILE_THREADS), 0,
+                           s, a, total);
+    }
     return hipGetLastError();
 }
 
