@@ -107,41 +107,161 @@ __global__ __launch_bounds__(256) void node_level_kernel(const digest* __restric
     out[i] = node_digest(l, r);
 }
 
-// Single workgroup: reduces m <= 2048 digests to the root, passing levels
-// through LDS and writing each level to the tree.
-constexpr int TOP_MAX = 2048;
-__global__ __launch_bounds__(1024) void merkle_top_kernel(digest* level, uint32_t m)
+// ---- four lanes per compression --------------------------------------------
+// Below about 2^17 nodes a level no longer fills the machine and its cost is
+// the latency of one compression.  There a compression is spread over the four
+// lanes of a quad: lane q holds column q of the 4x4 state (a = v[q],
+// b = v[4+q], c = v[8+q], d = v[12+q]), so the column step is one G per lane;
+// rotating b, c, d by one, two and three lanes inside the quad (DPP quad_perm)
+// lines the diagonals up for the second G of the round (RFC 7693 3.2).  The
+// message sits in LDS as sixteen 64-bit words (the upper eight zero for a
+// node) and each lane fetches the four words the schedule gives it in a round
+// through a per-lane table of byte offsets.
+constexpr uint8_t SIGMA[12][16] = {
+    {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15}, {14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3},
+    {11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4}, {7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8},
+    {9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13}, {2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9},
+    {12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11}, {13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10},
+    {6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5}, {10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0},
+    {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15}, {14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3}};
+
+// w[q][r]: byte offsets (8 * word index) of the four message words lane q uses
+// in round r: column x, column y, diagonal x, diagonal y, one per byte.
+struct QuadSchedule {
+    uint32_t w[4][12];
+};
+constexpr QuadSchedule make_quad_schedule()
 {
-    __shared__ digest s[TOP_MAX];
-    for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) s[i] = level[i];
+    QuadSchedule t{};
+    for (int q = 0; q < 4; q++)
+        for (int r = 0; r < 12; r++)
+            t.w[q][r] = (uint32_t)(8 * SIGMA[r][2 * q]) | ((uint32_t)(8 * SIGMA[r][2 * q + 1]) << 8) |
+                        ((uint32_t)(8 * SIGMA[r][8 + 2 * q]) << 16) | ((uint32_t)(8 * SIGMA[r][9 + 2 * q]) << 24);
+    return t;
+}
+__constant__ QuadSchedule g_quad_schedule = make_quad_schedule();
+
+template <int CTRL> __device__ __forceinline__ u64 quad_rotate(u64 x)
+{
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)x, CTRL, 0xf, 0xf, false);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)(x >> 32), CTRL, 0xf, 0xf, false);
+    return ((u64)hi << 32) | lo;
+}
+// quad_perm:[1,2,3,0], [2,3,0,1], [3,0,1,2]: lane i reads lane i+1, i+2, i+3 (mod 4)
+constexpr int QUAD_ROT1 = 0x39, QUAD_ROT2 = 0x4E, QUAD_ROT3 = 0x93;
+
+__device__ __forceinline__ void quad_g(u64& a, u64& b, u64& c, u64& d, u64 x, u64 y)
+{
+    a = a + b + x; d = rotr64(d ^ a, 32);
+    c = c + d;     b = rotr64(b ^ c, 24);
+    a = a + b + y; d = rotr64(d ^ a, 16);
+    c = c + d;     b = rotr64(b ^ c, 63);
+}
+
+struct QuadState {
+    u64 a0, b0, c0, d0;      // this lane's column of the initial state, d0 without the length
+    uint32_t sched[12];
+};
+
+__device__ __forceinline__ QuadState quad_state_init(uint32_t q)
+{
+    QuadState st;
+    const u64 iv_lo = q == 0 ? B2_IV0 : q == 1 ? B2_IV1 : q == 2 ? B2_IV2 : B2_IV3;
+    const u64 iv_hi = q == 0 ? B2_IV4 : q == 1 ? B2_IV5 : q == 2 ? B2_IV6 : B2_IV7;
+    st.a0 = iv_lo ^ (q == 0 ? 0x01010020ull : 0ull);     // digest_length=32, fanout=1, depth=1
+    st.b0 = iv_hi;
+    st.c0 = iv_lo;
+    st.d0 = q == 2 ? ~iv_hi : iv_hi;                      // single, final block
+#pragma clang loop unroll(full)
+    for (int r = 0; r < 12; r++) st.sched[r] = g_quad_schedule.w[q][r];
+    return st;
+}
+
+// One BLAKE2b-256 compression of the t-byte message at LDS address msg
+// (sixteen words, zero padded), by the four lanes of a quad; lane q returns
+// digest word q.
+__device__ __forceinline__ u64 quad_blake2b(const QuadState& st, uint32_t q, const uint8_t* msg, u64 t)
+{
+    u64 a = st.a0, b = st.b0, c = st.c0, d = st.d0 ^ (q == 0 ? t : 0ull);
+#pragma clang loop unroll(full)
+    for (int r = 0; r < 12; r++) {
+        const uint32_t sc = st.sched[r];
+        const u64 x0 = *(const u64*)(msg + (sc & 0xffu));
+        const u64 y0 = *(const u64*)(msg + ((sc >> 8) & 0xffu));
+        const u64 x1 = *(const u64*)(msg + ((sc >> 16) & 0xffu));
+        const u64 y1 = *(const u64*)(msg + (sc >> 24));
+        quad_g(a, b, c, d, x0, y0);
+        b = quad_rotate<QUAD_ROT1>(b); c = quad_rotate<QUAD_ROT2>(c); d = quad_rotate<QUAD_ROT3>(d);
+        quad_g(a, b, c, d, x1, y1);
+        b = quad_rotate<QUAD_ROT3>(b); c = quad_rotate<QUAD_ROT2>(c); d = quad_rotate<QUAD_ROT1>(d);
+    }
+    return st.a0 ^ a ^ c;
+}
+
+// Tail of a tree: every workgroup reduces TAIL_CHILDREN consecutive digests of
+// one level (or the whole level if it is smaller) to a single node, writing
+// every level it passes to the tree.  Levels alternate between two LDS buffers
+// of 128-byte message slots whose upper halves stay zero.
+constexpr uint32_t TAIL_CHILDREN = 512;
+constexpr uint32_t TAIL_THREADS = 1024;
+__global__ __launch_bounds__(TAIL_THREADS) void merkle_tail_kernel(digest* level, uint32_t m)
+{
+    __shared__ __align__(16) uint8_t buf_a[(TAIL_CHILDREN / 2) * 128];
+    __shared__ __align__(16) uint8_t buf_b[(TAIL_CHILDREN / 4) * 128];
+    const uint32_t t = threadIdx.x;
+    const uint32_t c_blk = m < TAIL_CHILDREN ? m : TAIL_CHILDREN;       // children per workgroup
+    {
+        const uint4 z = make_uint4(0, 0, 0, 0);
+        *(uint4*)(buf_a + (t >> 2) * 128 + 64 + (t & 3) * 16) = z;
+        if (t < TAIL_THREADS / 2) *(uint4*)(buf_b + (t >> 2) * 128 + 64 + (t & 3) * 16) = z;
+        // thread t carries bytes 16t..16t+15 of this workgroup's children into slot t/4
+        if (t < 2 * c_blk) {
+            const uint4* src = (const uint4*)(level + (size_t)blockIdx.x * c_blk);
+            *(uint4*)(buf_a + (t >> 2) * 128 + (t & 3) * 16) = src[t];
+        }
+    }
+    const uint32_t q = t & 3, h = t >> 2;
+    const QuadState st = quad_state_init(q);
     __syncthreads();
-    digest* out = level + m;
-    while (m > 1) {
-        const uint32_t half = m >> 1;
-        digest d;
-        const bool act = threadIdx.x < half;
-        if (act) {
-            d = node_digest(s[2 * threadIdx.x], s[2 * threadIdx.x + 1]);
-            out[threadIdx.x] = d;
+    uint8_t* in = buf_a;
+    uint8_t* out = buf_b;
+    size_t level_off = m;                       // digests from `level` to the level being written
+    size_t m_level = m >> 1;                    // its size
+    for (uint32_t p = c_blk >> 1; p >= 1; p >>= 1) {
+        if (h < p) {
+            const u64 w = quad_blake2b(st, q, in + h * 128, 64);
+            *(u64*)(out + (h >> 1) * 128 + (h & 1) * 32 + q * 8) = w;
+            level[level_off + (size_t)blockIdx.x * p + h].w[q] = w;
         }
         __syncthreads();
-        if (act) s[threadIdx.x] = d;
-        __syncthreads();
-        out += half;
-        m = half;
+        uint8_t* sw = in; in = out; out = sw;
+        level_off += m_level;
+        m_level >>= 1;
     }
 }
 
+// Levels wider than this many children run one thread per parent (full
+// throughput); narrower ones are latency bound and go to the tail kernel.
+constexpr size_t TAIL_MAX_CHILDREN = (size_t)1 << 17;
+
 hipError_t launch_merkle_reduce(digest* level, size_t m, hipStream_t s)
 {
-    while (m > (size_t)TOP_MAX) {
+    while (m > TAIL_MAX_CHILDREN) {
         const size_t half = m >> 1;
         hipLaunchKernelGGL(node_level_kernel, dim3((uint32_t)((half + 255) / 256)), dim3(256), 0, s, level,
                            level + m, half);
         level += m;
         m = half;
     }
-    if (m > 1) hipLaunchKernelGGL(merkle_top_kernel, dim3(1), dim3(1024), 0, s, level, (uint32_t)m);
+    while (m > 1) {
+        const size_t c_blk = m < TAIL_CHILDREN ? m : TAIL_CHILDREN;
+        hipLaunchKernelGGL(merkle_tail_kernel, dim3((uint32_t)(m / c_blk)), dim3(TAIL_THREADS), 0, s, level,
+                           (uint32_t)m);
+        // skip the levels just written: sizes m, m/2, ..., 2*(m/c_blk)
+        size_t sz = m;
+        while (sz > m / c_blk) { level += sz; sz >>= 1; }
+        m = sz;
+    }
     return hipGetLastError();
 }
 
