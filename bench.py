@@ -19,9 +19,8 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
-    if p not in sys.path:
-        sys.path.insert(0, p)
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
 
 LOG_N = 22
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak
@@ -46,6 +45,9 @@ def _events_ms(torch, fn, reps):
 def cpu_baseline(log_n: int, reps: int):
     """The C restatement (oracle/stark_oracle.c, one thread) on the same
     workload: forward + inverse NTT of 2^log_n elements."""
+    for p in (os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):   # the checker lives outside the package
+        if p not in sys.path:
+            sys.path.insert(0, p)
     import oracle_c as oc
     n = 1 << log_n
     x = oc.splitmix(n, 0x5741524B)
@@ -85,14 +87,13 @@ def main():
     dev = torch.device("cuda", local_rank if world > 1 else 0)
 
     from stark_amd import Context, GENERATOR
-    import oracle_c as oc                       # synthetic data generator + cpu_baseline leg only
-    import stark_oracle as so
+    from stark_amd.synth import field_vector
 
     ctx = Context(dev.index)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
 
     n = 1 << LOG_N
-    host = oc.splitmix(n, 0x5741524B + rank)
+    host = field_vector(n, 0x5741524B + rank)
     data = torch.from_numpy(host.view(np.int64)).to(dev)
     orig = data.clone()
 
@@ -157,7 +158,7 @@ def main():
         extra["ntt_2^22_fwd_Melem_s"] = round(n / extra["ntt_2^22_fwd_ms"] / 1e3, 1)
         # 2^24 forward / inverse
         n24 = 1 << 24
-        d24 = torch.from_numpy(oc.splitmix(n24, 24).view(np.int64)).to(dev)
+        d24 = torch.from_numpy(field_vector(n24, 24).view(np.int64)).to(dev)
         for _ in range(3):
             ctx.ntt_dev(d24, n24, False)
         extra["ntt_2^24_fwd_ms"] = round(_events_ms(torch, lambda: ctx.ntt_dev(d24, n24, False), 10), 4)
@@ -172,17 +173,14 @@ def main():
         torch.cuda.synchronize()
         extra["merkle_2^24_ms"] = round((time.perf_counter() - t0) / 3 * 1e3, 3)
         extra["merkle_2^24_Mhash_s"] = round((2 * n24 - 1) / extra["merkle_2^24_ms"] / 1e3, 1)
-        # FRI commit on a 2^24 codeword (blowup 4, 17 colinearity tests: 18 roots, 17 folds)
-        omega = so.primitive_nth_root(n24)
+        # FRI commit on a 2^24 codeword (blowup 4, 17 colinearity tests: 18 roots, 17 folds) through
+        # the C++ host mirror of Fri::commit: the Fiat-Shamir transcript is its native ProofStream
+        from stark_amd import hostlib
+        omega = hostlib.primitive_nth_root(n24)
 
         def fri_once():
-            ps = so.ProofStream()
-
-            def transcript(rnd, last, root):
-                ps.push(root.hex())
-                return None if last else so.fe_sample(ps.prover_fiat_shamir(32))
-            layers = ctx.fri_commit(d24, GENERATOR, omega, 4, 17, transcript, n=n24)
-            layers.free()
+            ps = hostlib.Stream()
+            hostlib.fri_commit_resident(d24.data_ptr(), n24, GENERATOR, omega, 4, 17, ps)
 
         fri_once()
         torch.cuda.synchronize()
@@ -191,10 +189,32 @@ def main():
             fri_once()
         torch.cuda.synchronize()
         extra["fri_commit_2^24_ms"] = round((time.perf_counter() - t0) / 3 * 1e3, 3)
+
+        # the same commit with the transcript in a Python callback over the C ABI
+        import hashlib
+
+        def fri_py_once():
+            objs = []
+
+            def transcript(rnd, last, root):
+                objs.append(root.hex())
+                if last:
+                    return None
+                ser = len(objs).to_bytes(8, "little") + b"".join(len(o).to_bytes(8, "little") + o.encode() for o in objs)
+                return int.from_bytes(hashlib.shake_256(ser).digest(32), "big") % ((407 << 119) + 1)
+            ctx.fri_commit(d24, GENERATOR, omega, 4, 17, transcript, n=n24).free()
+
+        fri_py_once()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            fri_py_once()
+        torch.cuda.synchronize()
+        extra["fri_commit_2^24_python_transcript_ms"] = round((time.perf_counter() - t0) / 3 * 1e3, 3)
         del d24
         # batched coset LDE: 16 of the 64 columns of config 3 (2^20 coefficients -> 2^22 points each)
         cols = 16
-        coeffs = torch.from_numpy(oc.splitmix(cols << 20, 3).view(np.int64)).to(dev)
+        coeffs = torch.from_numpy(field_vector(cols << 20, 3).view(np.int64)).to(dev)
         out = torch.empty((cols << 22, 2), dtype=torch.int64, device=dev)
         lde = lambda: ctx.coset_lde_batch_dev(coeffs, 1 << 20, 1 << 20, cols, 1 << 22, GENERATOR, out, 1 << 22)  # noqa: E731
         lde()
@@ -211,7 +231,7 @@ def main():
             eng = HipEngine(ctx)
             n24 = 1 << 24
             per = n24 // world
-            xl = torch.from_numpy(oc.splitmix(per, 1000 + rank).view(np.int64)).to(dev)
+            xl = torch.from_numpy(field_vector(per, 1000 + rank).view(np.int64)).to(dev)
             for _ in range(2):
                 fourstep_ntt(xl, n24, eng)
             barrier()
@@ -231,7 +251,7 @@ def main():
             multi["fourstep_ntt_2^24_transposed_out_ms"] = round((time.perf_counter() - t0) / reps * 1e3, 4)
             del xl
             mine = shard_columns(64, rank, world)
-            cl = torch.from_numpy(oc.splitmix(len(mine) << 20, 2000 + rank).view(np.int64)).to(dev)
+            cl = torch.from_numpy(field_vector(len(mine) << 20, 2000 + rank).view(np.int64)).to(dev)
             cl = cl.view(len(mine), 1 << 20, 2)
             lde_commit_columns(eng, cl, 64, 1 << 22, GENERATOR)
             barrier()

@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libstark_hip.so")
+# STARK_HIP_LIBRARY names another build of the same library (kernel experiments)
+LIB_PATH = os.environ.get("STARK_HIP_LIBRARY") or os.path.join(_HERE, "csrc", "libstark_hip.so")
 
 u64p = C.POINTER(C.c_uint64)
 u8p = C.POINTER(C.c_uint8)

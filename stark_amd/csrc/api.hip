@@ -79,7 +79,6 @@ struct stark_ctx {
     size_t scratch_elems = 0;
     std::multimap<size_t, void*> pool;                 // cached device blocks by size
     void* pinned = nullptr;                            // small pinned staging buffer (4 KiB)
-    fe* zero_block = nullptr;                          // 64 zero bytes on the device
 };
 
 struct stark_tree {
@@ -333,7 +332,6 @@ static int32_t run_ntt(stark_ctx* ctx, const fe* src, size_t src_stride, size_t 
             a.hi = t->hi;
             a.lo = t->lo;
             a.fin = t->fin;
-            a.zero_block = ctx->zero_block;
             a.log_n = log_n;
             a.log_s = log_s;
             a.log_s_next = (q + 1 < P) ? log_s - t->radices[q + 1] : 0;
@@ -446,8 +444,6 @@ extern "C" int32_t stark_ctx_create(int32_t device, stark_ctx** out)
     ctx->device = device;
     hipError_t e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipHostMalloc(&ctx->pinned, 4096, hipHostMallocDefault);
-    if (e == hipSuccess) e = hipMalloc((void**)&ctx->zero_block, 64);
-    if (e == hipSuccess) e = hipMemset(ctx->zero_block, 0, 64);
     if (e != hipSuccess) {
         delete ctx;
         return fail(STARK_EHIP, std::string("stark_ctx_create: ") + hipGetErrorString(e));
@@ -471,7 +467,6 @@ extern "C" void stark_ctx_destroy(stark_ctx* ctx)
     for (auto& kv : ctx->pool) (void)hipFree(kv.second);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
-    if (ctx->zero_block) (void)hipFree(ctx->zero_block);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -877,14 +872,18 @@ static int32_t fri_commit_impl(stark_ctx* ctx, const fe* cw_src, bool src_is_hos
 
     FRI_HIP(hipMemcpyAsync(L->cw[0], cw_src, N * sizeof(fe),
                            src_is_host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, ctx->stream));   // fri.rs:130
+    // Roots arrive through host-mapped pinned memory, written by the kernel that
+    // produces them; a one-leaf layer has no such kernel and is copied instead.
+    digest* root_mail = (digest*)((uint8_t*)ctx->pinned + 2048);
     FRI_HIP(launch_leaf_hash(L->cw[0], L->tree[0], N, ctx->stream));
+    FRI_HIP(launch_merkle_reduce(L->tree[0], N, ctx->stream, root_mail));                                  // fri.rs:119
     fe offset_r = of;
     for (size_t r = 0; r < rounds; r++) {
         const size_t n = L->len[r];
-        FRI_HIP(launch_merkle_reduce(L->tree[r], n, ctx->stream));                                     // fri.rs:119
-        FRI_HIP(hipMemcpyAsync(ctx->pinned, L->tree[r] + (2 * n - 2), 32, hipMemcpyDeviceToHost, ctx->stream));
+        if (n == 1)
+            FRI_HIP(hipMemcpyAsync(root_mail, L->tree[r], 32, hipMemcpyDeviceToHost, ctx->stream));
         FRI_HIP(hipStreamSynchronize(ctx->stream));
-        memcpy(L->roots[r].data(), ctx->pinned, 32);
+        memcpy(L->roots[r].data(), root_mail, 32);
         const bool last = (r == rounds - 1);
         uint64_t alpha_raw[2] = {0, 0};
         if (cb(user, (uint32_t)r, last ? 1 : 0, L->roots[r].data(), alpha_raw) != 0)                   // fri.rs:120,126-127
@@ -901,7 +900,7 @@ static int32_t fri_commit_impl(stark_ctx* ctx, const fe* cw_src, bool src_is_hos
         a.c_m = fold_constant(F, alpha, offset_r);
         a.half = n / 2;
         a.shift = (uint32_t)r;
-        FRI_HIP(launch_fri_fold(a, ctx->stream));                                                      // fri.rs:133-139
+        FRI_HIP(launch_fri_fold_commit(a, ctx->stream, root_mail));                                    // fri.rs:133-139,119
         offset_r = F.mul(offset_r, offset_r);                                                          // fri.rs:142
     }
 #undef FRI_HIP

@@ -148,64 +148,70 @@ STARK_HD fe5 mont_mul5(const fe5& a, const W& w)
 
 #if defined(__HIP_DEVICE_COMPILE__)
 // Hand-scheduled form of mont_mul5 for the device: one serial column chain on a
-// fixed accumulator pair (v[254:255]), 31 v_mad_i64_i32 + 10 v_and + 10
-// v_ashrrev_i64.  hipcc re-associates the C++ form into "sum the column's
+// fixed accumulator pair, 31 v_mad_i64_i32 + 10 v_and + 10 v_ashrrev_i64.  The
+// pair is named explicitly because the chain reads its low half on its own and
+// inline asm has no sub-register operand; v[166:167] is the top of the
+// 168-register budget of three waves per SIMD, so the pair itself never costs
+// occupancy.  hipcc re-associates the C++ form into "sum the column's
 // products, then add the carry", which costs one more 64-bit add per column.
 // WS selects where the twiddle limbs live: "s" (wave-uniform, scalar registers)
 // or "v".  VOP3 reads at most one scalar operand, which every line respects.
+#define F5_ACC "v[166:167]"
+#define F5_ACC_LO "v166"
+#define F5_ACC_HI "v167"
 #define STARK_MM5_BODY                                            \
-    "v_mad_i64_i32 v[254:255], vcc, %[a0], %[w0], 0\n\t"          \
-    "v_and_b32 %[m0], 0x3ffffff, v254\n\t"                        \
-    "v_ashrrev_i64 v[254:255], 26, v[254:255]\n\t"                \
-    "v_mad_i64_i32 v[254:255], vcc, %[a0], %[w1], v[254:255]\n\t" \
-    "v_mad_i64_i32 v[254:255], vcc, %[a1], %[w0], v[254:255]\n\t" \
-    "v_and_b32 %[m1], 0x3ffffff, v254\n\t"                        \
-    "v_ashrrev_i64 v[254:255], 26, v[254:255]\n\t"                \
-    "v_mad_i64_i32 v[254:255], vcc, %[a0], %[w2], v[254:255]\n\t" \
-    "v_mad_i64_i32 v[254:255], vcc, %[a1], %[w1], v[254:255]\n\t" \
-    "v_mad_i64_i32 v[254:255], vcc, %[a2], %[w0], v[254:255]\n\t" \
-    "v_and_b32 %[m2], 0x3ffffff, v254\n\t"                        \
-    "v_ashrrev_i64 v[254:255], 26, v[254:255]\n\t"                \
-    "v_mad_i64_i32 v[254:255], vcc, %[a0], %[w3], v[254:255]\n\t" \
-    "v_mad_i64_i32 v[254:255], vcc, %[a1], %[w2], v[254:255]\n\t" \
-    "v_mad_i64_i32 v[254:255], vcc, %[a2], %[w1], v[254:255]\n\t" \
-    "v_mad_i64_i32 v[254:255], vcc, %[a3], %[w0], v[254:255]\n\t" \
-    "v_and_b32 %[m3], 0x3ffffff, v254\n\t"                        \
-    "v_ashrrev_i64 v[254:255], 26, v[254:255]\n\t"                \
-    "v_mad_i64_i32 v[254:255], vcc, %[a0], %[w4], v[254:255]\n\t" \
-    "v_mad_i64_i32 v[254:255], vcc, %[a1], %[w3], v[254:255]\n\t" \
-    "v_mad_i64_i32 v[254:255], vcc, %[a2], %[w2], v[254:255]\n\t" \
-    "v_mad_i64_i32 v[254:255], vcc, %[a3], %[w1], v[254:255]\n\t" \
-    "v_mad_i64_i32 v[254:255], vcc, %[a4], %[w0], v[254:255]\n\t" \
-    "v_mad_i64_i32 v[254:255], vcc, %[m0], %[np4], v[254:255]\n\t" \
-    "v_and_b32 %[m0], 0x3ffffff, v254\n\t"                        \
-    "v_ashrrev_i64 v[254:255], 26, v[254:255]\n\t"                \
-    "v_mad_i64_i32 v[254:255], vcc, %[a1], %[w4], v[254:255]\n\t" \
-    "v_mad_i64_i32 v[254:255], vcc, %[a2], %[w3], v[254:255]\n\t" \
-    "v_mad_i64_i32 v[254:255], vcc, %[a3], %[w2], v[254:255]\n\t" \
-    "v_mad_i64_i32 v[254:255], vcc, %[a4], %[w1], v[254:255]\n\t" \
-    "v_mad_i64_i32 v[254:255], vcc, %[m1], %[np4], v[254:255]\n\t" \
-    "v_and_b32 %[m1], 0x3ffffff, v254\n\t"                        \
-    "v_ashrrev_i64 v[254:255], 26, v[254:255]\n\t"                \
-    "v_mad_i64_i32 v[254:255], vcc, %[a2], %[w4], v[254:255]\n\t" \
-    "v_mad_i64_i32 v[254:255], vcc, %[a3], %[w3], v[254:255]\n\t" \
-    "v_mad_i64_i32 v[254:255], vcc, %[a4], %[w2], v[254:255]\n\t" \
-    "v_mad_i64_i32 v[254:255], vcc, %[m2], %[np4], v[254:255]\n\t" \
-    "v_and_b32 %[r0], 0x3ffffff, v254\n\t"                        \
-    "v_ashrrev_i64 v[254:255], 26, v[254:255]\n\t"                \
-    "v_mad_i64_i32 v[254:255], vcc, %[a3], %[w4], v[254:255]\n\t" \
-    "v_mad_i64_i32 v[254:255], vcc, %[a4], %[w3], v[254:255]\n\t" \
-    "v_mad_i64_i32 v[254:255], vcc, %[m3], %[np4], v[254:255]\n\t" \
-    "v_and_b32 %[r1], 0x3ffffff, v254\n\t"                        \
-    "v_ashrrev_i64 v[254:255], 26, v[254:255]\n\t"                \
-    "v_mad_i64_i32 v[254:255], vcc, %[a4], %[w4], v[254:255]\n\t" \
-    "v_mad_i64_i32 v[254:255], vcc, %[m0], %[np4], v[254:255]\n\t" \
-    "v_and_b32 %[r2], 0x3ffffff, v254\n\t"                        \
-    "v_ashrrev_i64 v[254:255], 26, v[254:255]\n\t"                \
-    "v_mad_i64_i32 v[254:255], vcc, %[m1], %[np4], v[254:255]\n\t" \
-    "v_and_b32 %[r3], 0x3ffffff, v254\n\t"                        \
-    "v_ashrrev_i64 v[254:255], 26, v[254:255]\n\t"                \
-    "v_mov_b32 %[r4], v254"
+    "v_mad_i64_i32 " F5_ACC ", vcc, %[a0], %[w0], 0\n\t"          \
+    "v_and_b32 %[m0], 0x3ffffff, " F5_ACC_LO "\n\t"                        \
+    "v_ashrrev_i64 " F5_ACC ", 26, " F5_ACC "\n\t"                \
+    "v_mad_i64_i32 " F5_ACC ", vcc, %[a0], %[w1], " F5_ACC "\n\t" \
+    "v_mad_i64_i32 " F5_ACC ", vcc, %[a1], %[w0], " F5_ACC "\n\t" \
+    "v_and_b32 %[m1], 0x3ffffff, " F5_ACC_LO "\n\t"                        \
+    "v_ashrrev_i64 " F5_ACC ", 26, " F5_ACC "\n\t"                \
+    "v_mad_i64_i32 " F5_ACC ", vcc, %[a0], %[w2], " F5_ACC "\n\t" \
+    "v_mad_i64_i32 " F5_ACC ", vcc, %[a1], %[w1], " F5_ACC "\n\t" \
+    "v_mad_i64_i32 " F5_ACC ", vcc, %[a2], %[w0], " F5_ACC "\n\t" \
+    "v_and_b32 %[m2], 0x3ffffff, " F5_ACC_LO "\n\t"                        \
+    "v_ashrrev_i64 " F5_ACC ", 26, " F5_ACC "\n\t"                \
+    "v_mad_i64_i32 " F5_ACC ", vcc, %[a0], %[w3], " F5_ACC "\n\t" \
+    "v_mad_i64_i32 " F5_ACC ", vcc, %[a1], %[w2], " F5_ACC "\n\t" \
+    "v_mad_i64_i32 " F5_ACC ", vcc, %[a2], %[w1], " F5_ACC "\n\t" \
+    "v_mad_i64_i32 " F5_ACC ", vcc, %[a3], %[w0], " F5_ACC "\n\t" \
+    "v_and_b32 %[m3], 0x3ffffff, " F5_ACC_LO "\n\t"                        \
+    "v_ashrrev_i64 " F5_ACC ", 26, " F5_ACC "\n\t"                \
+    "v_mad_i64_i32 " F5_ACC ", vcc, %[a0], %[w4], " F5_ACC "\n\t" \
+    "v_mad_i64_i32 " F5_ACC ", vcc, %[a1], %[w3], " F5_ACC "\n\t" \
+    "v_mad_i64_i32 " F5_ACC ", vcc, %[a2], %[w2], " F5_ACC "\n\t" \
+    "v_mad_i64_i32 " F5_ACC ", vcc, %[a3], %[w1], " F5_ACC "\n\t" \
+    "v_mad_i64_i32 " F5_ACC ", vcc, %[a4], %[w0], " F5_ACC "\n\t" \
+    "v_mad_i64_i32 " F5_ACC ", vcc, %[m0], %[np4], " F5_ACC "\n\t" \
+    "v_and_b32 %[m0], 0x3ffffff, " F5_ACC_LO "\n\t"                        \
+    "v_ashrrev_i64 " F5_ACC ", 26, " F5_ACC "\n\t"                \
+    "v_mad_i64_i32 " F5_ACC ", vcc, %[a1], %[w4], " F5_ACC "\n\t" \
+    "v_mad_i64_i32 " F5_ACC ", vcc, %[a2], %[w3], " F5_ACC "\n\t" \
+    "v_mad_i64_i32 " F5_ACC ", vcc, %[a3], %[w2], " F5_ACC "\n\t" \
+    "v_mad_i64_i32 " F5_ACC ", vcc, %[a4], %[w1], " F5_ACC "\n\t" \
+    "v_mad_i64_i32 " F5_ACC ", vcc, %[m1], %[np4], " F5_ACC "\n\t" \
+    "v_and_b32 %[m1], 0x3ffffff, " F5_ACC_LO "\n\t"                        \
+    "v_ashrrev_i64 " F5_ACC ", 26, " F5_ACC "\n\t"                \
+    "v_mad_i64_i32 " F5_ACC ", vcc, %[a2], %[w4], " F5_ACC "\n\t" \
+    "v_mad_i64_i32 " F5_ACC ", vcc, %[a3], %[w3], " F5_ACC "\n\t" \
+    "v_mad_i64_i32 " F5_ACC ", vcc, %[a4], %[w2], " F5_ACC "\n\t" \
+    "v_mad_i64_i32 " F5_ACC ", vcc, %[m2], %[np4], " F5_ACC "\n\t" \
+    "v_and_b32 %[r0], 0x3ffffff, " F5_ACC_LO "\n\t"                        \
+    "v_ashrrev_i64 " F5_ACC ", 26, " F5_ACC "\n\t"                \
+    "v_mad_i64_i32 " F5_ACC ", vcc, %[a3], %[w4], " F5_ACC "\n\t" \
+    "v_mad_i64_i32 " F5_ACC ", vcc, %[a4], %[w3], " F5_ACC "\n\t" \
+    "v_mad_i64_i32 " F5_ACC ", vcc, %[m3], %[np4], " F5_ACC "\n\t" \
+    "v_and_b32 %[r1], 0x3ffffff, " F5_ACC_LO "\n\t"                        \
+    "v_ashrrev_i64 " F5_ACC ", 26, " F5_ACC "\n\t"                \
+    "v_mad_i64_i32 " F5_ACC ", vcc, %[a4], %[w4], " F5_ACC "\n\t" \
+    "v_mad_i64_i32 " F5_ACC ", vcc, %[m0], %[np4], " F5_ACC "\n\t" \
+    "v_and_b32 %[r2], 0x3ffffff, " F5_ACC_LO "\n\t"                        \
+    "v_ashrrev_i64 " F5_ACC ", 26, " F5_ACC "\n\t"                \
+    "v_mad_i64_i32 " F5_ACC ", vcc, %[m1], %[np4], " F5_ACC "\n\t" \
+    "v_and_b32 %[r3], 0x3ffffff, " F5_ACC_LO "\n\t"                        \
+    "v_ashrrev_i64 " F5_ACC ", 26, " F5_ACC "\n\t"                \
+    "v_mov_b32 %[r4], " F5_ACC_LO
 
 #define STARK_MM5_DEFINE(NAME, WS)                                                                            \
     template <class W>                                                                                        \
@@ -218,7 +224,7 @@ STARK_HD fe5 mont_mul5(const fe5& a, const W& w)
             : [a0] "v"(a.l[0]), [a1] "v"(a.l[1]), [a2] "v"(a.l[2]), [a3] "v"(a.l[3]), [a4] "v"(a.l[4]),       \
               [w0] WS(w.l[0]), [w1] WS(w.l[1]), [w2] WS(w.l[2]), [w3] WS(w.l[3]), [w4] WS(w.l[4]),            \
               [np4] "s"(-P4)                                                                                  \
-            : "vcc", "v254", "v255");                                                                         \
+            : "vcc", F5_ACC_LO, F5_ACC_HI);                                                                         \
         fe5 r;                                                                                                \
         r.l[0] = r0 + 1;                                                                                      \
         r.l[1] = r1;                                                                                          \

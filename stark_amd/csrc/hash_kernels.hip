@@ -204,27 +204,30 @@ __device__ __forceinline__ u64 quad_blake2b(const QuadState& st, uint32_t q, con
 // of 128-byte message slots whose upper halves stay zero.
 constexpr uint32_t TAIL_CHILDREN = 512;
 constexpr uint32_t TAIL_THREADS = 1024;
-__global__ __launch_bounds__(TAIL_THREADS) void merkle_tail_kernel(digest* level, uint32_t m)
+
+struct TailBuffers {
+    uint8_t a[(TAIL_CHILDREN / 2) * 128];
+    uint8_t b[(TAIL_CHILDREN / 4) * 128];
+};
+
+__device__ __forceinline__ void tail_zero_padding(TailBuffers& lds, uint32_t t)
 {
-    __shared__ __align__(16) uint8_t buf_a[(TAIL_CHILDREN / 2) * 128];
-    __shared__ __align__(16) uint8_t buf_b[(TAIL_CHILDREN / 4) * 128];
-    const uint32_t t = threadIdx.x;
-    const uint32_t c_blk = m < TAIL_CHILDREN ? m : TAIL_CHILDREN;       // children per workgroup
-    {
-        const uint4 z = make_uint4(0, 0, 0, 0);
-        *(uint4*)(buf_a + (t >> 2) * 128 + 64 + (t & 3) * 16) = z;
-        if (t < TAIL_THREADS / 2) *(uint4*)(buf_b + (t >> 2) * 128 + 64 + (t & 3) * 16) = z;
-        // thread t carries bytes 16t..16t+15 of this workgroup's children into slot t/4
-        if (t < 2 * c_blk) {
-            const uint4* src = (const uint4*)(level + (size_t)blockIdx.x * c_blk);
-            *(uint4*)(buf_a + (t >> 2) * 128 + (t & 3) * 16) = src[t];
-        }
-    }
-    const uint32_t q = t & 3, h = t >> 2;
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    *(uint4*)(lds.a + (t >> 2) * 128 + 64 + (t & 3) * 16) = z;
+    if (t < TAIL_THREADS / 2) *(uint4*)(lds.b + (t >> 2) * 128 + 64 + (t & 3) * 16) = z;
+}
+
+// lds.a holds this workgroup's c_blk children (child k in slot k/2, half k%2).
+// When the launch is a single workgroup its last node is the root, which is
+// also stored to root_out if that is not null (host-mapped memory).
+__device__ __forceinline__ void tail_reduce(TailBuffers& lds, digest* level, uint32_t m, uint32_t c_blk,
+                                            digest* root_out)
+{
+    const uint32_t t = threadIdx.x, q = t & 3, h = t >> 2;
     const QuadState st = quad_state_init(q);
     __syncthreads();
-    uint8_t* in = buf_a;
-    uint8_t* out = buf_b;
+    uint8_t* in = lds.a;
+    uint8_t* out = lds.b;
     size_t level_off = m;                       // digests from `level` to the level being written
     size_t m_level = m >> 1;                    // its size
     for (uint32_t p = c_blk >> 1; p >= 1; p >>= 1) {
@@ -232,6 +235,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void merkle_tail_kernel(digest* level
             const u64 w = quad_blake2b(st, q, in + h * 128, 64);
             *(u64*)(out + (h >> 1) * 128 + (h & 1) * 32 + q * 8) = w;
             level[level_off + (size_t)blockIdx.x * p + h].w[q] = w;
+            if (root_out && m_level == 1) root_out->w[q] = w;
         }
         __syncthreads();
         uint8_t* sw = in; in = out; out = sw;
@@ -240,11 +244,35 @@ __global__ __launch_bounds__(TAIL_THREADS) void merkle_tail_kernel(digest* level
     }
 }
 
+__global__ __launch_bounds__(TAIL_THREADS) void merkle_tail_kernel(digest* level, uint32_t m, digest* root_out)
+{
+    __shared__ __align__(16) TailBuffers lds;
+    const uint32_t t = threadIdx.x;
+    const uint32_t c_blk = m < TAIL_CHILDREN ? m : TAIL_CHILDREN;       // children per workgroup
+    tail_zero_padding(lds, t);
+    // thread t carries bytes 16t..16t+15 of this workgroup's children into slot t/4
+    if (t < 2 * c_blk) {
+        const uint4* src = (const uint4*)(level + (size_t)blockIdx.x * c_blk);
+        *(uint4*)(lds.a + (t >> 2) * 128 + (t & 3) * 16) = src[t];
+    }
+    tail_reduce(lds, level, m, c_blk, root_out);
+}
+
 // Levels wider than this many children run one thread per parent (full
 // throughput); narrower ones are latency bound and go to the tail kernel.
 constexpr size_t TAIL_MAX_CHILDREN = (size_t)1 << 17;
 
-hipError_t launch_merkle_reduce(digest* level, size_t m, hipStream_t s)
+// the levels one tail launch writes: sizes m, m/2, ..., 2*(m/c_blk)
+static void tail_advance(digest*& level, size_t& m)
+{
+    const size_t c_blk = m < TAIL_CHILDREN ? m : TAIL_CHILDREN;
+    const size_t m_out = m / c_blk;
+    size_t sz = m;
+    while (sz > m_out) { level += sz; sz >>= 1; }
+    m = m_out;
+}
+
+hipError_t launch_merkle_reduce(digest* level, size_t m, hipStream_t s, digest* root_out)
 {
     while (m > TAIL_MAX_CHILDREN) {
         const size_t half = m >> 1;
@@ -256,11 +284,8 @@ hipError_t launch_merkle_reduce(digest* level, size_t m, hipStream_t s)
     while (m > 1) {
         const size_t c_blk = m < TAIL_CHILDREN ? m : TAIL_CHILDREN;
         hipLaunchKernelGGL(merkle_tail_kernel, dim3((uint32_t)(m / c_blk)), dim3(TAIL_THREADS), 0, s, level,
-                           (uint32_t)m);
-        // skip the levels just written: sizes m, m/2, ..., 2*(m/c_blk)
-        size_t sz = m;
-        while (sz > m / c_blk) { level += sz; sz >>= 1; }
-        m = sz;
+                           (uint32_t)m, root_out);
+        tail_advance(level, m);
     }
     return hipGetLastError();
 }
@@ -271,11 +296,8 @@ hipError_t launch_merkle_reduce(digest* level, size_t m, hipStream_t s)
 // omega^-i comes from the hi/lo power tables of the top-level root w
 // (omega = w^(2^shift)); optionally the leaf digest of out[i] is produced in
 // the same pass so the next layer's codeword is not re-read for hashing.
-template <bool LEAF>
-__global__ __launch_bounds__(256) void fri_fold_kernel(FoldArgs a)
+__device__ __forceinline__ fe fold_one(const FoldArgs& a, size_t i)
 {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.half) return;
     fe x = a.cw[i], y = a.cw[a.half + i];
     fe sum = fe_half(fe_add(x, y));
     fe dif = fe_sub(x, y);
@@ -284,7 +306,15 @@ __global__ __launch_bounds__(256) void fri_fold_kernel(FoldArgs a)
     const uint32_t el = (uint32_t)(E & 255);
     if (el) w = mont_mul(w, a.lo[el]);
     w = mont_mul(w, a.c_m);
-    fe o = fe_add(sum, mont_mul(dif, w));
+    return fe_add(sum, mont_mul(dif, w));
+}
+
+template <bool LEAF>
+__global__ __launch_bounds__(256) void fri_fold_kernel(FoldArgs a)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.half) return;
+    fe o = fold_one(a, i);
     a.out[i] = o;
     if constexpr (LEAF) a.leaf_out[i] = leaf_digest(o.lo, o.hi);
 }
@@ -296,6 +326,44 @@ hipError_t launch_fri_fold(const FoldArgs& a, hipStream_t s)
     if (a.leaf_out) hipLaunchKernelGGL(fri_fold_kernel<true>, grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL(fri_fold_kernel<false>, grid, dim3(256), 0, s, a);
     return hipGetLastError();
+}
+
+// Small layers: fold, leaf digests and the first nine tree levels in one launch
+// (a.leaf_out is level 0 of the new layer's tree, a.half its leaf count).
+__global__ __launch_bounds__(TAIL_THREADS) void fri_fold_tail_kernel(FoldArgs a, digest* root_out)
+{
+    __shared__ __align__(16) TailBuffers lds;
+    const uint32_t t = threadIdx.x;
+    const uint32_t m = (uint32_t)a.half;
+    const uint32_t c_blk = m < TAIL_CHILDREN ? m : TAIL_CHILDREN;
+    tail_zero_padding(lds, t);
+    if (t < c_blk) {
+        const size_t i = (size_t)blockIdx.x * c_blk + t;
+        fe o = fold_one(a, i);
+        a.out[i] = o;
+        const digest d = leaf_digest(o.lo, o.hi);
+        a.leaf_out[i] = d;
+        *(digest*)(lds.a + (t >> 1) * 128 + (t & 1) * 32) = d;
+        if (root_out && m == 1) *root_out = d;
+    }
+    tail_reduce(lds, a.leaf_out, m, c_blk, root_out);
+}
+
+// Fold layer r into layer r+1 and build layer r+1's whole tree.
+hipError_t launch_fri_fold_commit(const FoldArgs& a, hipStream_t s, digest* root_out)
+{
+    if (a.half == 0 || !a.leaf_out) return hipErrorInvalidValue;
+    if (a.half > TAIL_MAX_CHILDREN) {
+        hipError_t e = launch_fri_fold(a, s);
+        if (e != hipSuccess) return e;
+        return launch_merkle_reduce(a.leaf_out, a.half, s, root_out);
+    }
+    const size_t c_blk = a.half < TAIL_CHILDREN ? a.half : TAIL_CHILDREN;
+    hipLaunchKernelGGL(fri_fold_tail_kernel, dim3((uint32_t)(a.half / c_blk)), dim3(TAIL_THREADS), 0, s, a, root_out);
+    digest* level = a.leaf_out;
+    size_t m = a.half;
+    tail_advance(level, m);
+    return launch_merkle_reduce(level, m, s, root_out);
 }
 
 __global__ void merkle_open_kernel(const digest* __restrict__ tree, size_t n, size_t index,

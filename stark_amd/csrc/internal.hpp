@@ -32,7 +32,6 @@ struct PassArgs {
     const tw5* fin;        // 1 (forward) or n^-1 (inverse): multiplier of the last pass's outputs
     const tw5* twist_hi;   // s^(256 i), first pass of a coset transform
     const tw5* twist_lo;   // s^i, i<256
-    const fe* zero_block;  // 16 zero bytes in device memory (padding source of the asynchronous copy)
     uint64_t src_batch_stride;   // elements between consecutive transforms of a batch
     uint64_t dst_batch_stride;
     uint64_t n_src;        // valid source elements (first pass zero-fills the rest)
@@ -79,7 +78,8 @@ hipError_t launch_leaf_hash_bytes(const uint8_t* flat, const uint64_t* offsets, 
                                   hipStream_t s);
 // Reduce a level of m digests (power of two) to the root, writing every level
 // contiguously after it.
-hipError_t launch_merkle_reduce(digest* level, size_t m, hipStream_t s);
+// root_out, if not null, also receives the root (device-accessible memory)
+hipError_t launch_merkle_reduce(digest* level, size_t m, hipStream_t s, digest* root_out = nullptr);
 
 struct FoldArgs {
     const fe* cw;          // N elements
@@ -92,6 +92,7 @@ struct FoldArgs {
     uint32_t shift;        // omega of this layer = w^(2^shift)
 };
 hipError_t launch_fri_fold(const FoldArgs& a, hipStream_t s);
+hipError_t launch_fri_fold_commit(const FoldArgs& a, hipStream_t s, digest* root_out);
 
 // Authentication path of `index` (merkle.rs:54-93): depth digests, sibling leaf first.
 hipError_t launch_merkle_open(const digest* tree, size_t n, size_t index, digest* path_out, hipStream_t s);

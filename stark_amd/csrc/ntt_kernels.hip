@@ -167,62 +167,101 @@ struct Geo {
     static constexpr int C = 1 << LOGC;         // columns (rows in PASS_LAST) per tile
     static constexpr int PITCH = (MODE == PASS_LAST) ? (C + 1) : C;
     static constexpr int TWSHIFT = 8 - (RA + 4);
-    static constexpr int LDS_ELEMS = R * PITCH; // >= 4096: also the staging area of the prefetch
+    static constexpr int KA_HALF = M1 / 2;      // the exchange runs in two phases of M1/2 values of ka
+    static constexpr int LDS_ELEMS = (R / 2) * PITCH;
 };
 
-// canonical loads -> lazy limbs, plus the coset twist of a first pass
+// canonical loads -> lazy limbs, plus the coset twist of a first pass.  The
+// twist factors are gathered four elements ahead of their use so that their
+// latency overlaps the multiplications of the previous four.
 template <int RA, int MODE, bool TWIST>
 __device__ __forceinline__ void unpack_tile(fe5 (&v)[16], const fe (&raw)[16], const PassArgs& a, uint32_t tx, int t)
 {
     using G = Geo<RA, MODE>;
-#pragma unroll
-    for (int i = 0; i < 16; i++) v[i] = unpack5(raw[i]);
     if constexpr (MODE == PASS_FIRST && TWIST) {
-#pragma unroll
-        for (int g = 0; g < G::G1; g++) {
+        const tw5* __restrict__ thi = a.twist_hi;
+        const tw5* __restrict__ tlo = a.twist_lo;
+        constexpr int B = 2;
+        tw5 wh[2][B], wl[2][B];
+        auto index_of = [&](int i) -> uint64_t {
+            const int g = i / G::M1, ja = i % G::M1;
             const int q1 = t + TILE_THREADS * g;
             const int jb = q1 >> G::LOGC, c = q1 & (G::C - 1);
             const uint64_t f = (uint64_t)tx * G::C + c;
             const uint64_t pre = f >> a.log_s;
             const uint64_t col = f & (((uint64_t)1 << a.log_s) - 1);
             const uint64_t base = (pre << (a.r + a.log_s)) + col;
-#pragma unroll
-            for (int ja = 0; ja < G::M1; ja++) {
-                const uint64_t idx = base + ((uint64_t)(ja * 16 + jb) << a.log_s);
-                if (idx < a.n_src)
-                    v[g * G::M1 + ja] = mont_mul5_v(
-                        v[g * G::M1 + ja], mont_mul5_v(*(const fe5*)&a.twist_hi[idx >> 8], a.twist_lo[idx & 255]));
+            return base + ((uint64_t)(ja * 16 + jb) << a.log_s);
+        };
+        auto issue = [&](int bt) {
+#pragma clang loop unroll(full)
+            for (int i = 0; i < B; i++) {
+                const uint64_t idx = index_of(bt * B + i);
+                if (idx < a.n_src) {
+                    wh[bt & 1][i] = thi[idx >> 8];
+                    wl[bt & 1][i] = tlo[idx & 255];
+                }
+            }
+        };
+        issue(0);
+#pragma clang loop unroll(full)
+        for (int bt = 0; bt < 16 / B; bt++) {
+            if (bt + 1 < 16 / B) issue(bt + 1);
+#pragma clang loop unroll(full)
+            for (int i = 0; i < B; i++) {
+                const int e = bt * B + i;
+                v[e] = unpack5(raw[e]);
+                if (index_of(e) < a.n_src)
+                    v[e] = mont_mul5_v(v[e], mont_mul5_v(*(const fe5*)&wh[bt & 1][i], wl[bt & 1][i]));
             }
         }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 16; i++) v[i] = unpack5(raw[i]);
     }
 }
 
 // round 1 (radix M1 over ja), inner twiddle w_R^(jb*ka), exchange through LDS;
-// on return v holds the 16 round-2 inputs of this thread.  Ends with every
-// thread's LDS reads issued and waited for, but NOT with a barrier.
+// on return v holds the 16 round-2 inputs of this thread.  The exchange runs in
+// two phases, each carrying the half of the tile with ka in one half of its
+// range, so the buffer is half a tile (32 KiB) and three workgroups fit a CU.
+// A thread's 16 inputs all have ka = t >> LOGC, so waves 0-1 collect theirs in
+// phase 0 and waves 2-3 in phase 1.  Ends with every thread's LDS reads issued
+// and waited for, but NOT with a barrier.
 template <int RA, int MODE>
 __device__ __forceinline__ void round1_exchange(fe5 (&v)[16], fe* lds, const tw5* s_tw256, const tw5* __restrict__ tw16,
                                                 int t)
 {
     using G = Geo<RA, MODE>;
     RoundOne<RA, G::G1>::run(v, tw16);
-#pragma unroll
-    for (int g = 0; g < G::G1; g++) {
-        const int q1 = t + TILE_THREADS * g;
-        int jb, c;
-        if constexpr (MODE == PASS_LAST) { c = q1 >> 4; jb = q1 & 15; }
-        else { jb = q1 >> G::LOGC; c = q1 & (G::C - 1); }
-#pragma unroll
-        for (int ka = 0; ka < G::M1; ka++) {
-            const int reg = g * G::M1 + brev_c(ka, RA);
-            const fe5 x = mont_mul5_v(v[reg], s_tw256[(jb * ka) << G::TWSHIFT]);
-            lds[(ka * 16 + jb) * G::PITCH + c] = finish(x);
+    const int ka2 = t >> G::LOGC, c2 = t & (G::C - 1);
+    const int my_phase = ka2 / G::KA_HALF;
+    fe rcv[16];
+#pragma clang loop unroll(full)
+    for (int ph = 0; ph < 2; ph++) {
+        if (ph > 0) lds_barrier();          // phase 0 fully read before it is overwritten
+#pragma clang loop unroll(full)
+        for (int g = 0; g < G::G1; g++) {
+            const int q1 = t + TILE_THREADS * g;
+            int jb, c;
+            if constexpr (MODE == PASS_LAST) { c = q1 >> 4; jb = q1 & 15; }
+            else { jb = q1 >> G::LOGC; c = q1 & (G::C - 1); }
+#pragma clang loop unroll(full)
+            for (int kh = 0; kh < G::KA_HALF; kh++) {
+                const int ka = ph * G::KA_HALF + kh;
+                const int reg = g * G::M1 + brev_c(ka, RA);
+                const fe5 x = mont_mul5_v(v[reg], s_tw256[(jb * ka) << G::TWSHIFT]);
+                lds[(kh * 16 + jb) * G::PITCH + c] = finish(x);
+            }
+        }
+        lds_barrier();
+        if (my_phase == ph) {
+#pragma clang loop unroll(full)
+            for (int jb = 0; jb < 16; jb++) rcv[jb] = lds[((ka2 % G::KA_HALF) * 16 + jb) * G::PITCH + c2];
         }
     }
-    lds_barrier();
-    const int ka2 = t >> G::LOGC, c2 = t & (G::C - 1);
-#pragma unroll
-    for (int jb = 0; jb < 16; jb++) v[jb] = unpack5(lds[(ka2 * 16 + jb) * G::PITCH + c2]);
+#pragma clang loop unroll(full)
+    for (int jb = 0; jb < 16; jb++) v[jb] = unpack5(rcv[jb]);
 }
 
 // round 2 (radix 16 over jb), outgoing twiddle, store
@@ -232,16 +271,21 @@ __device__ __forceinline__ void round2_store(fe5 (&v)[16], const PassArgs& a, fe
 {
     using G = Geo<RA, MODE>;
     constexpr int M1 = G::M1;
+    // The store addresses are recomputed here from values the compiler cannot
+    // tie to the load addresses of the start of the pass; otherwise it keeps 16
+    // address pairs alive across both rounds and spills some of them.
+    asm volatile("" : "+v"(t), "+s"(tx));
     const int ka2 = t >> G::LOGC, c2 = t & (G::C - 1);
-    ntt_dif_reg<4, 0>(v, tw16);
     if constexpr (MODE == PASS_LAST) {
+        ntt_dif_reg<4, 0>(v, tw16);
         const uint64_t b = (uint64_t)tx * G::C + c2;
         const uint32_t sh = a.log_n - a.r;
         const tw5 fin = *a.fin;
 #pragma unroll
         for (int kb = 0; kb < 16; kb++) {
-            const uint64_t k = ka2 + M1 * kb;
-            dst[(k << sh) + b] = finish(mont_mul5_s(v[brev_c(kb, 4)], fin));
+            uint32_t k = ka2 + M1 * kb;
+            asm volatile("" : "+v"(k));
+            dst[((uint64_t)k << sh) + b] = finish(mont_mul5_s(v[brev_c(kb, 4)], fin));
         }
     } else {
         const uint64_t f = (uint64_t)tx * G::C + c2;
@@ -253,22 +297,64 @@ __device__ __forceinline__ void round2_store(fe5 (&v)[16], const PassArgs& a, fe
         uint32_t bits_prev = 0;
         for (uint32_t u = 0; u < a.nprev; u++) bits_prev += a.rprev[u];
         const uint32_t k_prev = prefix_to_k(pre, a);
+        const tw5* __restrict__ hi = a.hi;
+        const tw5* __restrict__ lo = a.lo;
+        // The outgoing twiddles are gathered ahead of the butterflies (and, where
+        // two tables are involved, four elements ahead of their use): a gather
+        // issued next to its use would sit behind the previous element's store
+        // in the in-order memory counter and expose a full round trip per element.
         if constexpr (NEXT_LAST) {
             // S_next = 1: exponent j_next * K, split over the hi and lo tables
+            constexpr int B = 1;
+            tw5 wh[2][B], wl[2][B];
+            auto issue = [&](int bt) {
 #pragma clang loop unroll(full)
-            for (int kb = 0; kb < 16; kb++) {
-                const uint32_t k = ka2 + M1 * kb;
-                const uint32_t E = j_next * (k_prev + (k << bits_prev));
-                const fe5 w = mont_mul5_v(*(const fe5*)&a.hi[E >> a.h], a.lo[E & ((1u << a.h) - 1)]);
-                dst[base + ((uint64_t)k << a.log_s)] = finish(mont_mul5_v(v[brev_c(kb, 4)], w));
+                for (int i = 0; i < B; i++) {
+                    const uint32_t k = ka2 + M1 * (bt * B + i);
+                    const uint32_t E = j_next * (k_prev + (k << bits_prev));
+                    wh[bt & 1][i] = hi[E >> a.h];
+                    wl[bt & 1][i] = lo[E & ((1u << a.h) - 1)];
+                }
+            };
+            // (two tables: the first batch waits until the butterflies have released their registers)
+            ntt_dif_reg<4, 0>(v, tw16);
+            issue(0);
+#pragma clang loop unroll(full)
+            for (int bt = 0; bt < 16 / B; bt++) {
+                if (bt + 1 < 16 / B) issue(bt + 1);
+#pragma clang loop unroll(full)
+                for (int i = 0; i < B; i++) {
+                    const int kb = bt * B + i;
+                    uint32_t k = ka2 + M1 * kb;
+                    asm volatile("" : "+v"(k));        // address formed here, not 16 at once up front
+                    const fe5 w = mont_mul5_v(*(const fe5*)&wh[bt & 1][i], wl[bt & 1][i]);
+                    dst[base + ((uint64_t)k << a.log_s)] = finish(mont_mul5_v(v[brev_c(kb, 4)], w));
+                }
             }
         } else {
             const uint32_t sn = a.log_s_next - a.h;                // S_next / 2^h
+            constexpr int B = 2;
+            tw5 w[2][B];
+            auto issue = [&](int bt) {
 #pragma clang loop unroll(full)
-            for (int kb = 0; kb < 16; kb++) {
-                const uint32_t k = ka2 + M1 * kb;
-                const uint32_t E = (j_next * (k_prev + (k << bits_prev))) << sn;
-                dst[base + ((uint64_t)k << a.log_s)] = finish(mont_mul5_v(v[brev_c(kb, 4)], a.hi[E]));
+                for (int i = 0; i < B; i++) {
+                    const uint32_t k = ka2 + M1 * (bt * B + i);
+                    const uint32_t E = (j_next * (k_prev + (k << bits_prev))) << sn;
+                    w[bt & 1][i] = hi[E];
+                }
+            };
+            issue(0);
+            ntt_dif_reg<4, 0>(v, tw16);
+#pragma clang loop unroll(full)
+            for (int bt = 0; bt < 16 / B; bt++) {
+                if (bt + 1 < 16 / B) issue(bt + 1);
+#pragma clang loop unroll(full)
+                for (int i = 0; i < B; i++) {
+                    const int kb = bt * B + i;
+                    uint32_t k = ka2 + M1 * kb;
+                    asm volatile("" : "+v"(k));        // address formed here, not 16 at once up front
+                    dst[base + ((uint64_t)k << a.log_s)] = finish(mont_mul5_v(v[brev_c(kb, 4)], w[bt & 1][i]));
+                }
             }
         }
     }
@@ -280,10 +366,10 @@ __device__ __forceinline__ void round2_store(fe5 (&v)[16], const PassArgs& a, fe
 // applied to this pass's outputs, so every element leaves the pass through a
 // multiplication, which is what brings the lazy limbs back to a canonical
 // value; the last pass multiplies by `fin` (1, or n^-1 for the inverse).
-// One workgroup per tile; the second resident workgroup of the CU hides this
-// one's global-memory latency.
+// One workgroup per tile; three workgroups are resident per CU (168 registers,
+// 37-40 KiB of LDS each) and hide one another's memory and barrier waits.
 template <int RA, int MODE, bool TWIST, bool NEXT_LAST>
-__global__ __launch_bounds__(TILE_THREADS) void ntt_pass_kernel(PassArgs a, uint64_t total_tiles)
+__global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) void ntt_pass_kernel(PassArgs a)
 {
     using G = Geo<RA, MODE>;
     __shared__ fe lds[G::LDS_ELEMS];
@@ -292,7 +378,6 @@ __global__ __launch_bounds__(TILE_THREADS) void ntt_pass_kernel(PassArgs a, uint
     const tw5* __restrict__ tw16 = a.tw16;
     const uint32_t ltiles = a.log_n - 12;
     s_tw256[t] = a.tw256[t];
-    (void)total_tiles;
 
     const uint64_t tile = blockIdx.x;
     const uint64_t batch = tile >> ltiles;
@@ -306,125 +391,12 @@ __global__ __launch_bounds__(TILE_THREADS) void ntt_pass_kernel(PassArgs a, uint
     round2_store<RA, MODE, NEXT_LAST>(v, a, a.dst + batch * a.dst_batch_stride, tx, tw16, t);
 }
 
-// Asynchronous copy of one tile's 16 loads per thread straight into LDS
-// (global_load_lds: no destination registers).  Slot i of thread t lands at
-// stage[i*256 + t]; a wave's 64 lanes write 1 KiB contiguously, as the
-// instruction requires.  Zero padding of a first pass reads a zero block.
-template <int RA, int MODE>
-__device__ __forceinline__ void prefetch_tile(fe* stage, const PassArgs& a, uint64_t tile, int t)
-{
-    using G = Geo<RA, MODE>;
-    const uint32_t ltiles = a.log_n - 12;
-    const uint64_t batch = tile >> ltiles;
-    const uint32_t tx = (uint32_t)(tile & (((uint64_t)1 << ltiles) - 1));
-    const fe* __restrict__ src = a.src + batch * a.src_batch_stride;
-    const int wave_base = t & ~63;
-#pragma unroll
-    for (int g = 0; g < G::G1; g++) {
-        const int q1 = t + TILE_THREADS * g;
-        if constexpr (MODE == PASS_LAST) {
-            const int c = q1 >> 4, jb = q1 & 15;
-            const uint32_t b = tx * G::C + c;
-            const uint64_t row = (uint64_t)k_to_prefix(b, a) << a.r;
-#pragma unroll
-            for (int ja = 0; ja < G::M1; ja++) {
-                const fe* gp = src + row + ja * 16 + jb;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
-                                                 (__attribute__((address_space(3))) void*)&stage[(g * G::M1 + ja) * 256 + wave_base],
-                                                 16, 0, 0);
-            }
-        } else {
-            const int jb = q1 >> G::LOGC, c = q1 & (G::C - 1);
-            const uint64_t f = (uint64_t)tx * G::C + c;
-            const uint64_t pre = f >> a.log_s;
-            const uint64_t col = f & (((uint64_t)1 << a.log_s) - 1);
-            const uint64_t base = (pre << (a.r + a.log_s)) + col;
-#pragma unroll
-            for (int ja = 0; ja < G::M1; ja++) {
-                const uint64_t idx = base + ((uint64_t)(ja * 16 + jb) << a.log_s);
-                const fe* gp = src + idx;
-                if constexpr (MODE == PASS_FIRST) {
-                    if (idx >= a.n_src) gp = a.zero_block;
-                }
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
-                                                 (__attribute__((address_space(3))) void*)&stage[(g * G::M1 + ja) * 256 + wave_base],
-                                                 16, 0, 0);
-            }
-        }
-    }
-}
-
-// Persistent form: a workgroup walks tiles blockIdx.x, +gridDim.x, ... and
-// copies its NEXT tile into LDS asynchronously while it computes round 2 of
-// the current one.  The copy reuses the exchange buffer, which is idle from
-// the end of the round-2 reads until the next tile's round-1 writes, so
-// neither LDS nor registers grow and two workgroups stay resident per CU.
-template <int RA, int MODE, bool TWIST, bool NEXT_LAST>
-__global__ __launch_bounds__(TILE_THREADS) void ntt_pass_kernel_persist(PassArgs a, uint64_t total_tiles)
-{
-    using G = Geo<RA, MODE>;
-    __shared__ fe lds[G::LDS_ELEMS];
-    __shared__ tw5 s_tw256[256];
-    const int t = threadIdx.x;
-    const tw5* __restrict__ tw16 = a.tw16;
-    const uint32_t ltiles = a.log_n - 12;
-    s_tw256[t] = a.tw256[t];
-
-    uint64_t tile = blockIdx.x;
-    if (tile < total_tiles) prefetch_tile<RA, MODE>(lds, a, tile, t);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    for (; tile < total_tiles; tile += gridDim.x) {
-        const uint64_t batch = tile >> ltiles;
-        const uint32_t tx = (uint32_t)(tile & (((uint64_t)1 << ltiles) - 1));
-        fe raw[16];
-        fe5 v[16];
-        // this thread's own 16 slots (written by its own wave's copy instructions)
-#pragma unroll
-        for (int i = 0; i < 16; i++) raw[i] = lds[i * 256 + t];
-        unpack_tile<RA, MODE, TWIST>(v, raw, a, tx, t);
-        lds_barrier();      // staging area fully read (and s_tw256 staged) before the exchange overwrites it
-        round1_exchange<RA, MODE>(v, lds, s_tw256, tw16, t);
-        lds_barrier();      // exchange buffer fully read before the next copy lands in it
-        const bool more = tile + gridDim.x < total_tiles;
-        if (more) prefetch_tile<RA, MODE>(lds, a, tile + gridDim.x, t);
-        round2_store<RA, MODE, NEXT_LAST>(v, a, a.dst + batch * a.dst_batch_stride, tx, tw16, t);
-        // The copy is older than this tile's 16 stores and every table load has been consumed,
-        // so "all but the 16 youngest" means the copy has landed.
-        if (more) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    }
-}
-
-static uint32_t persistent_grid()
-{
-    static uint32_t cached = [] {
-        int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        return (uint32_t)(cus > 0 ? cus : 256) * 2;      // two resident workgroups per CU
-    }();
-    return cached;
-}
-
-static bool use_persistent()
-{
-    static const bool on = [] {
-        const char* e = getenv("STARK_NTT_PERSIST");
-        return e && e[0] == '1';
-    }();
-    return on;
-}
-
 template <int RA, int MODE, bool TWIST, bool NEXT_LAST>
 static hipError_t launch_one(const PassArgs& a, uint32_t n_batch, hipStream_t s)
 {
     const uint64_t total = (((uint64_t)1 << a.log_n) / TILE_ELEMS) * n_batch;
     if (total > 0x7fffffffull) return hipErrorInvalidValue;
-    if (use_persistent() && total > persistent_grid()) {
-        hipLaunchKernelGGL((ntt_pass_kernel_persist<RA, MODE, TWIST, NEXT_LAST>), dim3(persistent_grid()),
-                           dim3(TILE_THREADS), 0, s, a, total);
-    } else {
-        hipLaunchKernelGGL((ntt_pass_kernel<RA, MODE, TWIST, NEXT_LAST>), dim3((uint32_t)total), dim3(TILE_THREADS), 0,
-                           s, a, total);
-    }
+    hipLaunchKernelGGL((ntt_pass_kernel<RA, MODE, TWIST, NEXT_LAST>), dim3((uint32_t)total), dim3(TILE_THREADS), 0, s, a);
     return hipGetLastError();
 }
 

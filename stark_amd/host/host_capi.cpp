@@ -235,6 +235,26 @@ int sh_fri_commit(const uint64_t* cw, size_t n, const uint64_t* offset, const ui
             for (auto& l : layers) { stv(layers_out + 2 * off, l); off += l.size(); }
         return (int)layers.size();)
 }
+// commit of a device-resident codeword (device pointer from stark_dev_alloc on the process
+// context); the layers stay on the device and are released before returning
+int sh_fri_commit_resident(const void* cw_dev, size_t n, const uint64_t* offset, const uint64_t* omega, size_t expansion,
+                           size_t ncol, void* ps)
+{
+    GUARD(
+        Fri f = make_fri(offset, omega, n, expansion, ncol);
+        std::unique_ptr<LayersHandle> h = f.commit_resident((const uint64_t*)cw_dev, *static_cast<ProofStream*>(ps));
+        return (int)stark_fri_layers_count(h->l);)
+}
+// the process-wide device context the mirror runs on (for callers that stage device buffers)
+void* sh_context()
+{
+    try {
+        return (void*)context();
+    } catch (const std::exception& e) {
+        g_panic = e.what();
+        return nullptr;
+    }
+}
 int sh_fri_prove(const uint64_t* cw, size_t n, const uint64_t* offset, const uint64_t* omega, size_t expansion,
                  size_t ncol, void* ps, uint64_t* indices_out)
 {

@@ -750,6 +750,18 @@ struct Fri {
         ps.push(wire::json_field_vec(download(h->l, last)));                                 // :146
         return h;
     }
+    // commit a codeword that is already resident on the device (packed, n = domain_length)
+    std::unique_ptr<LayersHandle> commit_resident(const uint64_t* codeword_dev, ProofStream& ps) const
+    {
+        uint64_t off[2] = {(uint64_t)offset.value, (uint64_t)(offset.value >> 64)};
+        uint64_t om[2] = {(uint64_t)omega.value, (uint64_t)(omega.value >> 64)};
+        std::unique_ptr<LayersHandle> h(new LayersHandle());
+        check(stark_fri_commit_dev(context(), codeword_dev, domain_length, off, om, expansion_factor,
+                                   num_colinearity_tests, &Fri::on_root, &ps, &h->l));
+        size_t last = stark_fri_layers_count(h->l) - 1;
+        ps.push(wire::json_field_vec(download(h->l, last)));                                 // :146
+        return h;
+    }
     std::vector<std::vector<FieldElement>> commit(const std::vector<FieldElement>& codeword, ProofStream& ps) const
     {                                                                                       // :100-152
         std::unique_ptr<LayersHandle> h = commit_device(codeword, ps);

@@ -70,6 +70,33 @@ template <int KIND> __global__ __launch_bounds__(256) void chain_kernel(digest* 
     if (d.w[0] == 0x1234567) out[0] = d;
 }
 
+// node level with memory traffic: K parents per thread, grid-stride so a wave's loads stay coalesced
+template <int K, int BS> __global__ __launch_bounds__(BS) void level_kernel(const digest* __restrict__ in, digest* __restrict__ out, size_t m_out)
+{
+    const size_t stride = (size_t)gridDim.x * BS;
+    size_t i = (size_t)blockIdx.x * BS + threadIdx.x;
+    digest l[K], r[K];
+#pragma clang loop unroll(full)
+    for (int k = 0; k < K; k++) { size_t j = i + k * stride; if (j < m_out) { l[k] = in[2 * j]; r[k] = in[2 * j + 1]; } }
+#pragma clang loop unroll(disable)
+    for (int k = 0; k < K; k++) { size_t j = i + k * stride; if (j < m_out) out[j] = node_digest(l[k], r[k]); }
+}
+template <int K, int BS> int run_level(const char* name, const digest* in, digest* out, size_t m_out)
+{
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    const unsigned grid = (unsigned)((m_out + (size_t)K * BS - 1) / ((size_t)K * BS));
+    hipLaunchKernelGGL((level_kernel<K, BS>), dim3(grid), dim3(BS), 0, 0, in, out, m_out);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(e0));
+    for (int r = 0; r < 5; r++) hipLaunchKernelGGL((level_kernel<K, BS>), dim3(grid), dim3(BS), 0, 0, in, out, m_out);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+    printf("%-24s %8.3f ms/launch  %7.2f Ghash/s\n", name, ms / 5, 5.0 * m_out / (ms * 1e-3) / 1e9);
+    return 0;
+}
+
 template <int KIND> int run(const char* name, digest* buf)
 {
     const int blocks = 256 * 8 * 4;
@@ -93,5 +120,16 @@ int main()
     run<0>("leaf (compute only)", buf);
     run<1>("node (compute only)", buf);
     run<2>("node, alignbit rotations", buf);
+    const size_t m_out = (size_t)1 << 23;
+    digest *in, *out;
+    CHECK(hipMalloc(&in, 2 * m_out * sizeof(digest)));
+    CHECK(hipMalloc(&out, m_out * sizeof(digest)));
+    CHECK(hipMemset(in, 0x5a, 2 * m_out * sizeof(digest)));
+    run_level<1, 256>("level K=1 BS=256", in, out, m_out);
+    run_level<1, 64>("level K=1 BS=64", in, out, m_out);
+    run_level<1, 1024>("level K=1 BS=1024", in, out, m_out);
+    run_level<2, 256>("level K=2 BS=256", in, out, m_out);
+    run_level<4, 256>("level K=4 BS=256", in, out, m_out);
+    run_level<8, 256>("level K=8 BS=256", in, out, m_out);
     return 0;
 }
