@@ -13,7 +13,6 @@
 // coefficients of the first pass, and the padding zeros are never read.
 #include <hip/hip_runtime.h>
 
-#include <cstdlib>
 
 #include "field5.hpp"
 #include "internal.hpp"
@@ -224,19 +223,21 @@ __device__ __forceinline__ void unpack_tile(fe5 (&v)[16], const fe (&raw)[16], c
 // round 1 (radix M1 over ja), inner twiddle w_R^(jb*ka), exchange through LDS;
 // on return v holds the 16 round-2 inputs of this thread.  The exchange runs in
 // two phases, each carrying the half of the tile with ka in one half of its
-// range, so the buffer is half a tile (32 KiB) and three workgroups fit a CU.
+// range, so the buffer is half a tile and three workgroups fit a CU.  Elements
+// cross LDS as the five lazy limbs a multiplication leaves (20 bytes), which is
+// cheaper than packing to 16 bytes and unpacking again.
 // A thread's 16 inputs all have ka = t >> LOGC, so waves 0-1 collect theirs in
 // phase 0 and waves 2-3 in phase 1.  Ends with every thread's LDS reads issued
 // and waited for, but NOT with a barrier.
 template <int RA, int MODE>
-__device__ __forceinline__ void round1_exchange(fe5 (&v)[16], fe* lds, const tw5* s_tw256, const tw5* __restrict__ tw16,
+__device__ __forceinline__ void round1_exchange(fe5 (&v)[16], fe5* lds, const tw5* s_tw256, const tw5* __restrict__ tw16,
                                                 int t)
 {
     using G = Geo<RA, MODE>;
     RoundOne<RA, G::G1>::run(v, tw16);
     const int ka2 = t >> G::LOGC, c2 = t & (G::C - 1);
     const int my_phase = ka2 / G::KA_HALF;
-    fe rcv[16];
+    fe5 rcv[16];
 #pragma clang loop unroll(full)
     for (int ph = 0; ph < 2; ph++) {
         if (ph > 0) lds_barrier();          // phase 0 fully read before it is overwritten
@@ -250,8 +251,7 @@ __device__ __forceinline__ void round1_exchange(fe5 (&v)[16], fe* lds, const tw5
             for (int kh = 0; kh < G::KA_HALF; kh++) {
                 const int ka = ph * G::KA_HALF + kh;
                 const int reg = g * G::M1 + brev_c(ka, RA);
-                const fe5 x = mont_mul5_v(v[reg], s_tw256[(jb * ka) << G::TWSHIFT]);
-                lds[(kh * 16 + jb) * G::PITCH + c] = finish(x);
+                lds[(kh * 16 + jb) * G::PITCH + c] = mont_mul5_v(v[reg], s_tw256[(jb * ka) << G::TWSHIFT]);
             }
         }
         lds_barrier();
@@ -261,7 +261,7 @@ __device__ __forceinline__ void round1_exchange(fe5 (&v)[16], fe* lds, const tw5
         }
     }
 #pragma clang loop unroll(full)
-    for (int jb = 0; jb < 16; jb++) v[jb] = unpack5(rcv[jb]);
+    for (int jb = 0; jb < 16; jb++) v[jb] = rcv[jb];
 }
 
 // round 2 (radix 16 over jb), outgoing twiddle, store
@@ -367,12 +367,12 @@ __device__ __forceinline__ void round2_store(fe5 (&v)[16], const PassArgs& a, fe
 // multiplication, which is what brings the lazy limbs back to a canonical
 // value; the last pass multiplies by `fin` (1, or n^-1 for the inverse).
 // One workgroup per tile; three workgroups are resident per CU (168 registers,
-// 37-40 KiB of LDS each) and hide one another's memory and barrier waits.
+// 48-52 KiB of LDS each) and hide one another's memory and barrier waits.
 template <int RA, int MODE, bool TWIST, bool NEXT_LAST>
 __global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) void ntt_pass_kernel(PassArgs a)
 {
     using G = Geo<RA, MODE>;
-    __shared__ fe lds[G::LDS_ELEMS];
+    __shared__ fe5 lds[G::LDS_ELEMS];
     __shared__ tw5 s_tw256[256];
     const int t = threadIdx.x;
     const tw5* __restrict__ tw16 = a.tw16;
