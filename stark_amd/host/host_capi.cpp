@@ -7,6 +7,7 @@
 #include <string>
 
 #include "stark_host.hpp"
+#include "stark_prover.hpp"
 
 using namespace stark;
 
@@ -296,6 +297,112 @@ int sh_fri_verify(const uint64_t* offset, const uint64_t* omega, size_t n, size_
             *n_points = pts.size();
         }
         return ok ? 1 : 0;)
+}
+
+// ---- univariate_poly.rs algebra (coefficients highest first) -------------------------------
+// op: 0 add, 1 sub, 2 mul, 3 div, 4 compose, 5 pow (b[0] = exponent), 6 zeroifier_domain(a), 7 neg
+int sh_poly_op(int op, const uint64_t* a, size_t na, const uint64_t* b, size_t nb, uint64_t* out, size_t* nout)
+{
+    GUARD(
+        Polynomial pa{ldv(a, na)}, pb{ldv(b, nb)}, r;
+        switch (op) {
+        case 0: r = pa + pb; break;
+        case 1: r = pa - pb; break;
+        case 2: r = pa * pb; break;
+        case 3: r = pa / pb; break;
+        case 4: r = pa.compose(pb); break;
+        case 5: r = pa.pow(((u128)b[1] << 64) | b[0]); break;
+        case 6: r = Polynomial::zeroifier_domain(pa.coeffs); break;
+        case 7: r = -pa; break;
+        default: throw Panic("bad op");
+        }
+        if (out) stv(out, r.coeffs);
+        *nout = r.coeffs.size();
+        return 0;)
+}
+
+// Polynomial::save then Polynomial::load through `path`; returns the file's bytes
+int sh_poly_save_load(const uint64_t* a, size_t na, const char* path, uint64_t* out, size_t* nout)
+{
+    GUARD(
+        Polynomial{ldv(a, na)}.save(path);
+        Polynomial r = Polynomial::load(path);
+        stv(out, r.coeffs);
+        *nout = r.coeffs.size();
+        return 0;)
+}
+
+// ---- rescue_prime.rs -----------------------------------------------------------------------
+// round_constants: 108 elements, mds / mds_inv: 4 elements each (row major), alpha_inv: 1 element
+int sh_rescue_params(uint64_t* round_constants, uint64_t* mds, uint64_t* mds_inv, uint64_t* alpha_inv)
+{
+    GUARD(
+        RescuePrime rp;
+        stv(round_constants, rp.round_constants);
+        for (int i = 0; i < 2; i++)
+            for (int j = 0; j < 2; j++) {
+                st(mds + 2 * (2 * i + j), rp.MDS[i][j]);
+                st(mds_inv + 2 * (2 * i + j), rp.MDS_inv[i][j]);
+            }
+        alpha_inv[0] = (uint64_t)rp.alpha_inv;
+        alpha_inv[1] = (uint64_t)(rp.alpha_inv >> 64);
+        return 0;)
+}
+int sh_rescue_hash(const uint64_t* in, uint64_t* out)
+{
+    GUARD(st(out, RescuePrime().hash(ld(in))); return 0;)
+}
+// number of stored terms of each transition constraint, and each one's value at a point of 5 elements
+int sh_rescue_air(const uint64_t* omicron, const uint64_t* point5, uint64_t* n_terms, uint64_t* values)
+{
+    GUARD(
+        RescuePrime rp;
+        std::vector<MPolynomial> air = rp.transition_constraints(ld(omicron));
+        std::vector<FieldElement> pt = ldv(point5, 5);
+        for (size_t i = 0; i < air.size(); i++) {
+            n_terms[i] = air[i].dict.size();
+            st(values + 2 * i, air[i].eval(pt));
+        }
+        return (int)air.size();)
+}
+
+// ---- stark.rs ------------------------------------------------------------------------------
+// Proof that output = RescuePrime::hash(input) (the flow of stark.rs:731-776).  `random` feeds
+// the prover's draws in order, 17 bytes each; returns the number of bytes consumed.
+int sh_stark_rescue_prove(const uint64_t* input, size_t expansion, size_t ncol, size_t security, const uint8_t* random,
+                          size_t n_random, uint8_t* proof_out, size_t* proof_len, uint64_t* output)
+{
+    GUARD(
+        RescuePrime rp;
+        FieldElement in = ld(input), out = rp.hash(in);
+        Stark stark(expansion, ncol, security, rp.m, rp.N + 1);
+        size_t used = 0;
+        RandomSource rng = [&](uint8_t* dst, size_t n) {
+            if (used + n > n_random) throw Panic("random bytes exhausted");
+            std::memcpy(dst, random + used, n);
+            used += n;
+        };
+        std::vector<uint8_t> proof =
+            stark.prove(rp.trace(in), rp.transition_constraints(stark.omicron), rp.boundary_constraints(out), rng);
+        if (proof_out) {
+            if (*proof_len < proof.size()) throw Panic("proof buffer too small");
+            std::memcpy(proof_out, proof.data(), proof.size());
+        }
+        *proof_len = proof.size();
+        if (output) st(output, out);
+        return (int)used;)
+}
+// 1 accept / 0 reject / -1 panic
+int sh_stark_rescue_verify(const uint64_t* output, size_t expansion, size_t ncol, size_t security, const uint8_t* proof,
+                           size_t proof_len)
+{
+    GUARD(
+        RescuePrime rp;
+        Stark stark(expansion, ncol, security, rp.m, rp.N + 1);
+        return stark.verify(std::vector<uint8_t>(proof, proof + proof_len), rp.transition_constraints(stark.omicron),
+                            rp.boundary_constraints(ld(output)))
+                   ? 1
+                   : 0;)
 }
 
 }  // extern "C"

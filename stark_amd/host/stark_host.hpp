@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <array>
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
 #include <memory>
 #include <stdexcept>
@@ -242,6 +243,32 @@ struct Scanner {
     }
 };
 
+inline FieldElement scan_field_element(Scanner& sc)                            // {"value":[sign,[digits]]}
+{
+    sc.expect('{');
+    sc.key("value");
+    sc.expect('[');
+    int64_t sign = sc.integer();
+    sc.expect(',');
+    sc.expect('[');
+    u128 v = 0;
+    int k = 0;
+    if (!sc.accept(']')) {
+        do {
+            v |= (u128)(uint32_t)sc.integer() << (32 * k++);
+        } while (sc.accept(','));
+        sc.expect(']');
+    }
+    sc.expect(']');
+    sc.expect('}');
+    FieldElement e = FieldElement::from(v);
+    return sign < 0 ? -e : e;
+}
+inline FieldElement json_field_element_parse(const std::string& str)           // stark.rs:538,566
+{
+    Scanner sc(str);
+    return scan_field_element(sc);
+}
 inline std::vector<FieldElement> json_field_vec_parse(const std::string& str)   // fri.rs:271
 {
     Scanner sc(str);
@@ -249,24 +276,7 @@ inline std::vector<FieldElement> json_field_vec_parse(const std::string& str)   
     sc.expect('[');
     if (!sc.accept(']')) {
         do {
-            sc.expect('{');
-            sc.key("value");
-            sc.expect('[');
-            int64_t sign = sc.integer();
-            sc.expect(',');
-            sc.expect('[');
-            u128 v = 0;
-            int k = 0;
-            if (!sc.accept(']')) {
-                do {
-                    v |= (u128)(uint32_t)sc.integer() << (32 * k++);
-                } while (sc.accept(','));
-                sc.expect(']');
-            }
-            sc.expect(']');
-            sc.expect('}');
-            FieldElement e = FieldElement::from(v);
-            out.push_back(sign < 0 ? -e : e);
+            out.push_back(scan_field_element(sc));
         } while (sc.accept(','));
         sc.expect(']');
     }
@@ -547,6 +557,117 @@ struct Polynomial {
             for (size_t j = 0; j < o.coeffs.size(); j++) r.coeffs[i + j] = r.coeffs[i + j] + coeffs[i] * o.coeffs[j];
         return r;
     }
+    bool is_zero() const                                                                    // :88-94
+    {
+        for (const FieldElement& c : coeffs)
+            if (!c.is_zero()) return false;
+        return true;
+    }
+    Polynomial operator-(const Polynomial& o) const                                         // :345-400
+    {
+        Polynomial r;
+        if (o.coeffs.size() > coeffs.size()) {
+            size_t diff = o.coeffs.size() - coeffs.size();
+            for (size_t i = 0; i < diff; i++) r.coeffs.push_back(FieldElement::zero() - o.coeffs[i]);
+            for (size_t i = 0; i < coeffs.size(); i++) r.coeffs.push_back(coeffs[i] - o.coeffs[diff + i]);
+        } else {
+            size_t diff = coeffs.size() - o.coeffs.size();
+            for (size_t i = 0; i < diff; i++) r.coeffs.push_back(coeffs[i]);
+            for (size_t i = 0; i < o.coeffs.size(); i++) r.coeffs.push_back(coeffs[diff + i] - o.coeffs[i]);
+        }
+        return r;
+    }
+    Polynomial operator-() const                                                            // :423-434
+    {
+        Polynomial r;
+        for (const FieldElement& c : coeffs) r.coeffs.push_back(FieldElement::zero() - c);
+        return r;
+    }
+    // Long division exactly as written (:437-484): the quotient has deg(self) -
+    // deg(rhs) + 1 coefficients, position i of the dividend VECTOR pairs with
+    // quotient[i], and the divisor's first stored coefficient is its leading one.
+    Polynomial operator/(const Polynomial& rhs) const
+    {
+        if (rhs.is_zero()) throw Panic("Attempted to divide by zero polynomial.");
+        size_t nd = degree(), dd = rhs.degree();
+        if (dd > nd) return Polynomial{{FieldElement::zero()}};
+        std::vector<FieldElement> dividend = coeffs;
+        size_t qd = nd - dd;
+        Polynomial q;
+        q.coeffs.assign(qd + 1, FieldElement::zero());
+        FieldElement lead_inv = rhs.coeffs[0].inverse();
+        for (size_t i = 0; i <= qd; i++) {
+            if (i < dividend.size() && !dividend[i].is_zero()) {
+                FieldElement c = dividend[i] * lead_inv;
+                q.coeffs[i] = c;
+                for (size_t j = 0; j < rhs.coeffs.size(); j++)
+                    if (i + j < dividend.size()) dividend[i + j] = dividend[i + j] - c * rhs.coeffs[j];
+            }
+        }
+        return q;
+    }
+    // :285-303.  The reference walks the bit positions below the leading zeros of
+    // a u128 exponent; squaring [1] gives [1], so for exponents under 2^64 that
+    // is the ordinary left-to-right ladder.
+    Polynomial pow(u128 exponent) const
+    {
+        if (is_zero()) return Polynomial{{FieldElement::zero()}};
+        if (exponent == 0) return Polynomial{{FieldElement::one()}};
+        if (exponent >> 64) throw Panic("Polynomial::pow: exponent out of range");
+        Polynomial acc{{FieldElement::one()}};
+        int top = 63;
+        while (!((exponent >> top) & 1)) top--;
+        for (int i = top; i >= 0; i--) {
+            acc = acc * acc;
+            if ((exponent >> i) & 1) acc = acc * *this;
+        }
+        return acc;
+    }
+    Polynomial compose(const Polynomial& other) const                                       // :203-221
+    {
+        if (is_zero()) return Polynomial{{FieldElement::zero()}};
+        Polynomial result{{FieldElement::zero()}}, power{{FieldElement::one()}};
+        for (auto it = coeffs.rbegin(); it != coeffs.rend(); ++it) {
+            result = result + Polynomial{{*it}} * power;
+            power = power * other;
+        }
+        return result;
+    }
+    static Polynomial zeroifier_domain(const std::vector<FieldElement>& domain)             // :254-264
+    {
+        Polynomial x{{FieldElement::one(), FieldElement::zero()}}, acc{{FieldElement::one()}};
+        for (const FieldElement& d : domain) acc = acc * (x - Polynomial{{d}});
+        return acc;
+    }
+    // the file format of save / load (:224-238): serde_json of { coeffs: Vec<FieldElement> }
+    std::string to_json() const { return "{\"coeffs\":" + wire::json_field_vec(coeffs) + "}"; }
+    static Polynomial from_json(const std::string& str)
+    {
+        size_t a = str.find('['), b = str.rfind(']');
+        if (str.compare(0, 10, "{\"coeffs\":") != 0 || a == std::string::npos || b == std::string::npos || b < a)
+            throw Panic("invalid polynomial file");
+        return Polynomial{wire::json_field_vec_parse(str.substr(a, b - a + 1))};
+    }
+    void save(const std::string& filename) const
+    {
+        FILE* f = std::fopen(filename.c_str(), "wb");
+        if (!f) throw Panic("cannot create " + filename);
+        std::string j = to_json();
+        size_t w = std::fwrite(j.data(), 1, j.size(), f);
+        std::fclose(f);
+        if (w != j.size()) throw Panic("short write to " + filename);
+    }
+    static Polynomial load(const std::string& filename)
+    {
+        FILE* f = std::fopen(filename.c_str(), "rb");
+        if (!f) throw Panic("cannot open " + filename);
+        std::string j;
+        char buf[4096];
+        size_t r;
+        while ((r = std::fread(buf, 1, sizeof buf, f)) > 0) j.append(buf, r);
+        std::fclose(f);
+        return from_json(j);
+    }
     static Polynomial lagrange_traditional(const std::vector<FieldElement>& x, const std::vector<FieldElement>& y)
     {                                                                                       // :104-124,147-164
         Polynomial p;
@@ -822,7 +943,15 @@ struct Fri {
 
     std::vector<size_t> prove(const std::vector<FieldElement>& codeword, ProofStream& ps) const   // :212-254
     {
-        std::unique_ptr<LayersHandle> h = commit_device(codeword, ps);
+        return prove_on(commit_device(codeword, ps), ps);
+    }
+    // prove for a codeword that already lives on the device (packed, domain_length elements)
+    std::vector<size_t> prove_resident(const uint64_t* codeword_dev, ProofStream& ps) const
+    {
+        return prove_on(commit_resident(codeword_dev, ps), ps);
+    }
+    std::vector<size_t> prove_on(std::unique_ptr<LayersHandle> h, ProofStream& ps) const
+    {
         size_t layers = stark_fri_layers_count(h->l);
         std::vector<size_t> top = sample_indices(ps.prover_fiat_shamir(32), stark_fri_layer_len(h->l, 0) / 2,
                                                  stark_fri_layer_len(h->l, layers - 1), num_colinearity_tests);
