@@ -24,10 +24,16 @@ if ROOT not in sys.path:
 
 LOG_N = 22
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak
-# HBM-side bytes per ntt_pass_kernel launch at 2^22, from the rocprofv3 PMC passes kept in
-# profiles/r01_ntt22_pmc_{fetch,write}.csv: mean over the three pass kernels of
-# 2 x FETCH_SIZE (gfx950 counts half of a wide read stream) + WRITE_SIZE.
-PMC_TRAFFIC_BYTES_PER_LAUNCH = (2 * 35840 + 65536) * 1024
+# From the rocprofv3 PMC passes kept under profiles/ (r01_ntt22_pmc_{fetch,write,valu}.csv; see
+# profiles/r01_summary.txt), means over the three pass kernels of a 2^22 transform:
+# HBM-side bytes per launch = 2 x FETCH_SIZE (gfx950 counts half of a wide read stream) + WRITE_SIZE
+PMC_TRAFFIC_BYTES_PER_LAUNCH = (2 * 36515 + 69130) * 1024
+# 64-bit-class VALU wave-instructions per launch (v_mad_i64_i32 and the 64-bit shifts/adds of the
+# Montgomery product), and all VALU wave-instructions per launch
+PMC_INT64_WAVE_INSTR_PER_LAUNCH = 11430571
+PMC_VALU_WAVE_INSTR_PER_LAUNCH = 19632811
+# a SIMD issues one 64-bit-class integer instruction per 4 cycles: 1024 SIMDs x 2.4 GHz / 4
+VALU_INT64_PEAK_GINSTR_S = 1024 * 2.4 / 4
 
 
 def _events_ms(torch, fn, reps):
@@ -147,7 +153,14 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": PMC_TRAFFIC_BYTES_PER_LAUNCH,
                          "algorithmic_bytes": int(alg_bytes),
                          "kernel": "ntt_pass_kernel (3 launches per transform)",
-                         "avg_launch_us": round(avg_launch_ms * 1e3, 2)},
+                         "avg_launch_us": round(avg_launch_ms * 1e3, 2),
+                         # the butterfly passes are integer-multiply bound: 64-bit multiply-add issue
+                         # rate (counter SQ_INSTS_VALU_INT64) against one such instruction per SIMD per 4 cycles
+                         "valu_int64": {"achieved": round(PMC_INT64_WAVE_INSTR_PER_LAUNCH / (avg_launch_ms * 1e-3) / 1e9, 1),
+                                        "peak": VALU_INT64_PEAK_GINSTR_S, "unit": "Gwave-instr/s",
+                                        "frac": round(PMC_INT64_WAVE_INSTR_PER_LAUNCH / (avg_launch_ms * 1e-3) / 1e9
+                                                      / VALU_INT64_PEAK_GINSTR_S, 4),
+                                        "all_valu_wave_instr_per_launch": PMC_VALU_WAVE_INSTR_PER_LAUNCH}},
         }
 
     extra = {}

@@ -4,14 +4,12 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
-    sys.path.insert(0, p)
+sys.path.insert(0, ROOT)
 import numpy as np
 import torch
 
-import oracle_c as oc
-import stark_oracle as so
-from stark_amd import Context, GENERATOR
+from stark_amd import Context, GENERATOR, hostlib
+from stark_amd.synth import field_vector
 
 what = sys.argv[1]
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
@@ -20,29 +18,24 @@ ctx = Context(0)
 ctx.set_stream(torch.cuda.current_stream().cuda_stream)
 if what in ("ntt24", "ntt22"):
     n = 1 << int(what[3:])
-    d = torch.from_numpy(oc.splitmix(n, 1).view(np.int64)).to(dev)
+    d = torch.from_numpy(field_vector(n, 1).view(np.int64)).to(dev)
     for _ in range(reps):
         ctx.ntt_dev(d, n, False)
         ctx.ntt_dev(d, n, True)
 elif what == "merkle24":
     n = 1 << 24
-    d = torch.from_numpy(oc.splitmix(n, 1).view(np.int64)).to(dev)
+    d = torch.from_numpy(field_vector(n, 1).view(np.int64)).to(dev)
     for _ in range(reps):
         ctx.merkle_commit_fe_dev(d, n)
 elif what == "fri24":
     n = 1 << 24
-    d = torch.from_numpy(oc.splitmix(n, 1).view(np.int64)).to(dev)
-    omega = so.primitive_nth_root(n)
+    d = torch.from_numpy(field_vector(n, 1).view(np.int64)).to(dev)
+    omega = hostlib.primitive_nth_root(n)
     for _ in range(reps):
-        ps = so.ProofStream()
-
-        def transcript(rnd, last, root):
-            ps.push(root.hex())
-            return None if last else so.fe_sample(ps.prover_fiat_shamir(32))
-        ctx.fri_commit(d, GENERATOR, omega, 4, 17, transcript, n=n).free()
+        hostlib.fri_commit_resident(d.data_ptr(), n, GENERATOR, omega, 4, 17, hostlib.Stream())
 elif what == "lde":
     cols = 16
-    c = torch.from_numpy(oc.splitmix(cols << 20, 3).view(np.int64)).to(dev)
+    c = torch.from_numpy(field_vector(cols << 20, 3).view(np.int64)).to(dev)
     out = torch.empty((cols << 22, 2), dtype=torch.int64, device=dev)
     for _ in range(reps):
         ctx.coset_lde_batch_dev(c, 1 << 20, 1 << 20, cols, 1 << 22, GENERATOR, out, 1 << 22)
