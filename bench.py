@@ -3,7 +3,7 @@
 
 Contract: python bench.py --gpus N --steps K --warmup W  ->  ONE JSON line on
 rank 0.  A step is one forward + one inverse 2^22-point NTT over the 128-bit
-field (BASELINE.json configs[1]) on device-resident data; with N > 1 every rank
+field on device-resident data; with N > 1 every rank
 transforms its own vector (independent units, no collective: weak scaling) and
 `value` is the whole-job rate.  The same line carries the roofline of the
 dominant kernel family and the CPU restatement timed on the host cores, plus

@@ -6,13 +6,14 @@
 // through the C ABI; scalars, the transcript and the verifier stay here.
 //
 // The reference's toolchain (Rust) is not available where this was written,
-// so this C++ layer is what exercises the boundary; INTEGRATION.md shows the
-// Rust binding that replaces it.
+// so this C++ layer is what exercises the boundary; a Rust binding of the same
+// entry points replaces it where cargo is available.
 #pragma once
 #include <algorithm>
 #include <array>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <stdexcept>
@@ -38,11 +39,15 @@ inline void check(int32_t rc)
 }
 
 // One lazily created device context per process (the reference has no state).
+// One process drives one GPU: STARK_DEVICE, else the launcher's LOCAL_RANK, else 0.
 inline stark_ctx* context()
 {
     static stark_ctx* ctx = [] {
+        const char* e = std::getenv("STARK_DEVICE");
+        if (!e || !*e) e = std::getenv("LOCAL_RANK");
+        int dev = (e && *e) ? std::atoi(e) : 0;
         stark_ctx* c = nullptr;
-        check(stark_ctx_create(0, &c));
+        check(stark_ctx_create(dev, &c));
         return c;
     }();
     return ctx;

@@ -57,7 +57,7 @@ def test_ntt_4096_u64_inputs_golden(ctx, golden):
 
 
 def test_ntt_2_22_config(ctx):
-    """BASELINE config: single 2^22-point forward + inverse, bit-exact."""
+    """The headline size: single 2^22-point forward + inverse, bit-exact."""
     n = 1 << 22
     x = oc.splitmix(n, 22)
     f = ctx.ntt(x)
@@ -142,7 +142,7 @@ def test_coset_lde_batch_columns(ctx):
 
 
 def test_coset_lde_full_size_column(ctx):
-    """BASELINE config 3 shape, one column: 2^20 coefficients -> 2^22 points."""
+    """One column of the batched-LDE workload: 2^20 coefficients -> 2^22 points."""
     c = oc.splitmix(1 << 20, 20)
     out = ctx.coset_lde_batch(c, 1 << 22, G)[0]
     assert np.array_equal(out, oc.coset_lde(c, 1 << 22, G))
@@ -308,7 +308,7 @@ def test_fri_commit_errors(ctx):
 
 
 def test_fri_commit_2_24_full_size(ctx):
-    """BASELINE config 4: 2^24 codeword, blowup 4, 17 colinearity tests: 18
+    """The FRI headline workload: 2^24 codeword, blowup 4, 17 colinearity tests: 18
     roots, 17 folds.  Checked against the C restatement root by root."""
     n = 1 << 24
     coeffs = oc.splitmix(n // 4, 2424)
