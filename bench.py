@@ -235,34 +235,15 @@ def main():
         extra["coset_lde_Melem_s_out"] = round((cols << 22) / extra["coset_lde_16x2^20_to_2^22_ms"] / 1e3, 1)
         del coeffs, out
 
-    # multi-GPU side measurements (all ranks take part): the four-step 2^24 transform whose
-    # transposes are RCCL all-to-alls, and config 3's 64 columns sharded column-wise
+    # side measurements every rank takes part in: the batched-LDE workload (64 columns of 2^20
+    # coefficients -> 2^22 points each, one Merkle root per column), sharded column-wise with no
+    # data-path collective (only the 32-byte roots are gathered); and, with more than one GPU, the
+    # four-step 2^24 transform whose transposes are RCCL all-to-alls
     multi = {}
-    if world > 1 and not args.no_extra:
+    if not args.no_extra:
         try:
             from stark_amd.distributed import HipEngine, fourstep_ntt, lde_commit_columns, shard_columns
             eng = HipEngine(ctx)
-            n24 = 1 << 24
-            per = n24 // world
-            xl = torch.from_numpy(field_vector(per, 1000 + rank).view(np.int64)).to(dev)
-            for _ in range(2):
-                fourstep_ntt(xl, n24, eng)
-            barrier()
-            t0 = time.perf_counter()
-            reps = 5
-            for _ in range(reps):
-                fourstep_ntt(xl, n24, eng)
-            barrier()
-            ms = (time.perf_counter() - t0) / reps * 1e3
-            multi["fourstep_ntt_2^24_ms"] = round(ms, 4)
-            multi["fourstep_ntt_2^24_Melem_s"] = round(n24 / ms / 1e3, 1)
-            barrier()
-            t0 = time.perf_counter()
-            for _ in range(reps):
-                fourstep_ntt(xl, n24, eng, natural_output=False)
-            barrier()
-            multi["fourstep_ntt_2^24_transposed_out_ms"] = round((time.perf_counter() - t0) / reps * 1e3, 4)
-            del xl
             mine = shard_columns(64, rank, world)
             cl = torch.from_numpy(field_vector(len(mine) << 20, 2000 + rank).view(np.int64)).to(dev)
             cl = cl.view(len(mine), 1 << 20, 2)
@@ -275,6 +256,28 @@ def main():
             multi["lde_commit_64x2^20_to_2^22_ms"] = round(ms, 3)
             multi["lde_commit_Melem_s_out"] = round((64 << 22) / ms / 1e3, 1)
             del cl
+            if world > 1:
+                n24 = 1 << 24
+                per = n24 // world
+                xl = torch.from_numpy(field_vector(per, 1000 + rank).view(np.int64)).to(dev)
+                for _ in range(2):
+                    fourstep_ntt(xl, n24, eng)
+                barrier()
+                t0 = time.perf_counter()
+                reps = 5
+                for _ in range(reps):
+                    fourstep_ntt(xl, n24, eng)
+                barrier()
+                ms = (time.perf_counter() - t0) / reps * 1e3
+                multi["fourstep_ntt_2^24_ms"] = round(ms, 4)
+                multi["fourstep_ntt_2^24_Melem_s"] = round(n24 / ms / 1e3, 1)
+                barrier()
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    fourstep_ntt(xl, n24, eng, natural_output=False)
+                barrier()
+                multi["fourstep_ntt_2^24_transposed_out_ms"] = round((time.perf_counter() - t0) / reps * 1e3, 4)
+                del xl
         except Exception as e:  # noqa: BLE001 - side measurements must not lose the headline line
             multi["error"] = repr(e)
 

@@ -877,7 +877,10 @@ static int32_t fri_commit_impl(stark_ctx* ctx, const fe* cw_src, bool src_is_hos
     digest* root_mail = (digest*)((uint8_t*)ctx->pinned + 2048);
     FRI_HIP(launch_leaf_hash(L->cw[0], L->tree[0], N, ctx->stream));
     FRI_HIP(launch_merkle_reduce(L->tree[0], N, ctx->stream, root_mail));                                  // fri.rs:119
-    fe offset_r = of;
+    // 2^-1 alpha offset_r^-1 per round: the two inverses are taken once (a Fermat inverse is ~400
+    // host multiplications) and offset_r^-1 = (offset^-1)^(2^r) follows by squaring (fri.rs:142)
+    const fe two_inv = F.inverse(fe{2, 0});
+    fe offset_inv_r = F.inverse(of);
     for (size_t r = 0; r < rounds; r++) {
         const size_t n = L->len[r];
         if (n == 1)
@@ -897,11 +900,11 @@ static int32_t fri_commit_impl(stark_ctx* ctx, const fe* cw_src, bool src_is_hos
         a.leaf_out = L->tree[r + 1];
         a.hi = (const fe*)pt->hi;
         a.lo = (const fe*)pt->lo;
-        a.c_m = fold_constant(F, alpha, offset_r);
+        a.c_m = F.to_mont(F.mul(F.mul(two_inv, alpha), offset_inv_r));
         a.half = n / 2;
         a.shift = (uint32_t)r;
         FRI_HIP(launch_fri_fold_commit(a, ctx->stream, root_mail));                                    // fri.rs:133-139,119
-        offset_r = F.mul(offset_r, offset_r);                                                          // fri.rs:142
+        offset_inv_r = F.mul(offset_inv_r, offset_inv_r);
     }
 #undef FRI_HIP
     *layers_out = L.release();
