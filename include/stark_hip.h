@@ -113,6 +113,12 @@ int32_t stark_merkle_commit_fe(stark_ctx* ctx, const uint64_t* elems, size_t n, 
                                stark_tree** tree_out);
 int32_t stark_merkle_commit_fe_dev(stark_ctx* ctx, const uint64_t* elems_dev, size_t n, uint8_t root[32],
                                    stark_tree** tree_out);
+/* One Merkle::commit per column of a batch, as Stark::prove commits every
+ * boundary-quotient codeword (stark.rs:293-306): column c is the n elements at
+ * elems_dev + c*col_stride (elements), roots_out receives n_cols x 32 bytes
+ * (host).  All columns go through the same launches; trees are not retained. */
+int32_t stark_merkle_roots_fe_batch_dev(stark_ctx* ctx, const uint64_t* elems_dev, size_t n, size_t n_cols,
+                                        size_t col_stride, uint8_t* roots_out);
 /* Merkle::commit(&Vec<Vec<u8>>) for arbitrary byte leaves: leaf i is
  * flat[offsets[i] .. offsets[i+1]) (host pointers). */
 int32_t stark_merkle_commit_bytes(stark_ctx* ctx, const uint8_t* flat, const uint64_t* offsets, size_t n,

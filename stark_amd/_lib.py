@@ -42,6 +42,7 @@ SIGNATURES = {
     "stark_vec_mul_dev": (i32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, sz]),
     "stark_merkle_commit_fe": (i32, [C.c_void_p, C.c_void_p, sz, u8p, voidpp]),
     "stark_merkle_commit_fe_dev": (i32, [C.c_void_p, C.c_void_p, sz, u8p, voidpp]),
+    "stark_merkle_roots_fe_batch_dev": (i32, [C.c_void_p, C.c_void_p, sz, sz, sz, C.c_void_p]),
     "stark_merkle_commit_bytes": (i32, [C.c_void_p, C.c_void_p, C.c_void_p, sz, u8p, voidpp]),
     "stark_merkle_open": (i32, [C.c_void_p, sz, u8p, szp]),
     "stark_tree_num_leaves": (sz, [C.c_void_p]),

@@ -408,6 +408,34 @@ static int32_t tree_build(stark_ctx* ctx, const fe* elems_dev, size_t n, uint8_t
     return STARK_OK;
 }
 
+extern "C" int32_t stark_merkle_roots_fe_batch_dev(stark_ctx* ctx, const uint64_t* elems_dev, size_t n, size_t n_cols,
+                                                   size_t col_stride, uint8_t* roots_out)
+{
+    if (!ctx || !elems_dev || !roots_out) return fail(STARK_EARG, "null argument");
+    const int log_n = log2_exact(n);
+    if (log_n < 0) return fail(STARK_ENOTPOW2, "length must be power of two");
+    if (n_cols == 0) return STARK_OK;
+    if (col_stride < n) return fail(STARK_ELENGTH, "column stride shorter than the column");
+    // columns are committed in groups whose trees (2n-1 digests each, not retained) fit 4 GiB of scratch
+    const size_t tree_digests = 2 * n - 1;
+    size_t group = ((size_t)4 << 30) / (tree_digests * sizeof(digest));
+    if (group == 0) group = 1;
+    if (group > n_cols) group = n_cols;
+    DevBuf scratch(ctx);
+    ST_TRY(scratch.alloc(group * tree_digests * sizeof(digest)));
+    digest* level0 = (digest*)scratch.p;
+    for (size_t c0 = 0; c0 < n_cols; c0 += group) {
+        const size_t g = n_cols - c0 < group ? n_cols - c0 : group;
+        digest* roots_dev = nullptr;
+        HIP_TRY(launch_leaf_hash_batch((const fe*)elems_dev + c0 * col_stride, col_stride, level0, (uint32_t)log_n, g,
+                                       ctx->stream));
+        HIP_TRY(launch_merkle_reduce(level0, g * n, ctx->stream, nullptr, g, &roots_dev));
+        HIP_TRY(hipMemcpyAsync(roots_out + 32 * c0, roots_dev, 32 * g, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    return STARK_OK;
+}
+
 static int32_t tree_open(stark_ctx* ctx, const digest* tree, size_t n, size_t index, uint8_t* path_out,
                          size_t* depth_out)
 {

@@ -22,6 +22,28 @@ __global__ __launch_bounds__(256) void leaf_hash_kernel(const fe* __restrict__ e
     out[i] = leaf_digest(x.lo, x.hi);
 }
 
+// Leaves of a batch of columns: column c is the n elements at elems + c * col_stride
+// (n a power of two); digests land column after column in level0.
+__global__ __launch_bounds__(256) void leaf_hash_batch_kernel(const fe* __restrict__ elems, size_t col_stride,
+                                                              digest* __restrict__ out, uint32_t log_n, size_t total)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const size_t c = i >> log_n, j = i & (((size_t)1 << log_n) - 1);
+    fe x = elems[c * col_stride + j];
+    out[i] = leaf_digest(x.lo, x.hi);
+}
+
+hipError_t launch_leaf_hash_batch(const fe* elems, size_t col_stride, digest* level0, uint32_t log_n, size_t n_cols,
+                                  hipStream_t s)
+{
+    const size_t total = n_cols << log_n;
+    if ((total + 255) / 256 > 0x7fffffffull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(leaf_hash_batch_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, s, elems, col_stride,
+                       level0, log_n, total);
+    return hipGetLastError();
+}
+
 hipError_t launch_leaf_hash(const fe* elems, digest* level0, size_t n, hipStream_t s)
 {
     hipLaunchKernelGGL(leaf_hash_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, elems, level0, n);
@@ -244,11 +266,11 @@ __device__ __forceinline__ void tail_reduce(TailBuffers& lds, digest* level, uin
     }
 }
 
-__global__ __launch_bounds__(TAIL_THREADS) void merkle_tail_kernel(digest* level, uint32_t m, digest* root_out)
+__global__ __launch_bounds__(TAIL_THREADS) void merkle_tail_kernel(digest* level, uint32_t m, uint32_t c_blk,
+                                                                   digest* root_out)
 {
     __shared__ __align__(16) TailBuffers lds;
-    const uint32_t t = threadIdx.x;
-    const uint32_t c_blk = m < TAIL_CHILDREN ? m : TAIL_CHILDREN;       // children per workgroup
+    const uint32_t t = threadIdx.x;                                     // c_blk = children per workgroup
     tail_zero_padding(lds, t);
     // thread t carries bytes 16t..16t+15 of this workgroup's children into slot t/4
     if (t < 2 * c_blk) {
@@ -263,30 +285,37 @@ __global__ __launch_bounds__(TAIL_THREADS) void merkle_tail_kernel(digest* level
 constexpr size_t TAIL_MAX_CHILDREN = (size_t)1 << 17;
 
 // the levels one tail launch writes: sizes m, m/2, ..., 2*(m/c_blk)
-static void tail_advance(digest*& level, size_t& m)
+static void tail_advance(digest*& level, size_t& m, size_t c_blk)
 {
-    const size_t c_blk = m < TAIL_CHILDREN ? m : TAIL_CHILDREN;
     const size_t m_out = m / c_blk;
     size_t sz = m;
     while (sz > m_out) { level += sz; sz >>= 1; }
     m = m_out;
 }
 
-hipError_t launch_merkle_reduce(digest* level, size_t m, hipStream_t s, digest* root_out)
+// Reduces a level of m digests that holds n_trees trees side by side (m / n_trees digests each,
+// a power of two) until every tree is down to its root; the roots end up next to one another and
+// *roots_dev, if not null, receives their address.
+hipError_t launch_merkle_reduce(digest* level, size_t m, hipStream_t s, digest* root_out, size_t n_trees,
+                                digest** roots_dev)
 {
-    while (m > TAIL_MAX_CHILDREN) {
+    size_t m_tree = m / n_trees;
+    while (m_tree > 1 && m > TAIL_MAX_CHILDREN) {
         const size_t half = m >> 1;
         hipLaunchKernelGGL(node_level_kernel, dim3((uint32_t)((half + 255) / 256)), dim3(256), 0, s, level,
                            level + m, half);
         level += m;
         m = half;
+        m_tree >>= 1;
     }
-    while (m > 1) {
-        const size_t c_blk = m < TAIL_CHILDREN ? m : TAIL_CHILDREN;
+    while (m_tree > 1) {
+        const size_t c_blk = m_tree < TAIL_CHILDREN ? m_tree : TAIL_CHILDREN;
         hipLaunchKernelGGL(merkle_tail_kernel, dim3((uint32_t)(m / c_blk)), dim3(TAIL_THREADS), 0, s, level,
-                           (uint32_t)m, root_out);
-        tail_advance(level, m);
+                           (uint32_t)m, (uint32_t)c_blk, n_trees == 1 ? root_out : nullptr);
+        tail_advance(level, m, c_blk);
+        m_tree /= c_blk;
     }
+    if (roots_dev) *roots_dev = level;
     return hipGetLastError();
 }
 
@@ -362,7 +391,7 @@ hipError_t launch_fri_fold_commit(const FoldArgs& a, hipStream_t s, digest* root
     hipLaunchKernelGGL(fri_fold_tail_kernel, dim3((uint32_t)(a.half / c_blk)), dim3(TAIL_THREADS), 0, s, a, root_out);
     digest* level = a.leaf_out;
     size_t m = a.half;
-    tail_advance(level, m);
+    tail_advance(level, m, c_blk);
     return launch_merkle_reduce(level, m, s, root_out);
 }
 

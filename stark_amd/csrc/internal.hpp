@@ -78,8 +78,12 @@ hipError_t launch_leaf_hash_bytes(const uint8_t* flat, const uint64_t* offsets, 
                                   hipStream_t s);
 // Reduce a level of m digests (power of two) to the root, writing every level
 // contiguously after it.
-// root_out, if not null, also receives the root (device-accessible memory)
-hipError_t launch_merkle_reduce(digest* level, size_t m, hipStream_t s, digest* root_out = nullptr);
+hipError_t launch_leaf_hash_batch(const fe* elems, size_t col_stride, digest* level0, uint32_t log_n, size_t n_cols,
+                                  hipStream_t s);
+// `level` holds n_trees trees side by side; root_out, if not null (single tree only), also receives
+// the root (device-accessible memory); *roots_dev, if not null, the address of the adjacent roots
+hipError_t launch_merkle_reduce(digest* level, size_t m, hipStream_t s, digest* root_out = nullptr,
+                                size_t n_trees = 1, digest** roots_dev = nullptr);
 
 struct FoldArgs {
     const fe* cw;          // N elements

@@ -214,6 +214,15 @@ class Context:
                                                       C.byref(th) if keep_tree else None))
         return (bytes(root), Tree(self, th)) if keep_tree else bytes(root)
 
+    def merkle_roots_fe_batch_dev(self, dptr, n: int, n_cols: int, col_stride: Optional[int] = None) -> List[bytes]:
+        """One Merkle::commit per column (column c = n elements at dptr + c*col_stride), all columns
+        through the same launches; returns the n_cols roots."""
+        roots = (C.c_uint8 * (32 * max(n_cols, 1)))()
+        self._chk(self.lib.stark_merkle_roots_fe_batch_dev(self.h, _ptr(dptr), n, n_cols,
+                                                           n if col_stride is None else col_stride, roots))
+        raw = bytes(roots)
+        return [raw[32 * c:32 * (c + 1)] for c in range(n_cols)]
+
     def merkle_commit_bytes(self, leaves: Sequence[bytes], keep_tree: bool = False):
         flat = np.frombuffer(b"".join(leaves) or b"\0", dtype=np.uint8).copy()
         offs = np.zeros(len(leaves) + 1, dtype=np.uint64)

@@ -46,6 +46,11 @@ class HipEngine:
     def merkle_root(self, column: torch.Tensor) -> bytes:
         return self.ctx.merkle_commit_fe_dev(column, column.shape[0])
 
+    def merkle_roots(self, columns: torch.Tensor) -> List[bytes]:
+        """Roots of all columns of a contiguous (cols, n, 2) batch in one call."""
+        cols, n, _ = columns.shape
+        return self.ctx.merkle_roots_fe_batch_dev(columns, n, cols, n)
+
 
 # ---------------------------------------------------------------------------
 # column sharding (no data-path collective)
@@ -85,7 +90,10 @@ def lde_commit_columns(engine, coeffs_local: torch.Tensor, n_cols: int, n_out: i
     coeffs_local: this rank's columns (shard_columns order), shape
     (local_cols, n_coeffs, 2) int64.  Returns (codewords_local, all_roots)."""
     cw = engine.coset_lde(coeffs_local, n_out, offset)
-    local_roots = [engine.merkle_root(cw[i]) for i in range(cw.shape[0])]
+    if hasattr(engine, "merkle_roots") and cw.shape[0] > 0:
+        local_roots = engine.merkle_roots(cw)
+    else:
+        local_roots = [engine.merkle_root(cw[i]) for i in range(cw.shape[0])]
     return cw, gather_roots(local_roots, n_cols, group)
 
 

@@ -218,6 +218,33 @@ def test_merkle_full_size_root(ctx):
     assert ctx.merkle_commit_fe(x) == oc.merkle_commit_fe(x)
 
 
+@pytest.mark.parametrize("log_n,cols,pad", [(0, 3, 0), (1, 5, 1), (4, 7, 0), (9, 3, 5), (10, 64, 0), (13, 9, 3),
+                                            (17, 2, 0), (18, 3, 0)])
+def test_merkle_roots_batch_vs_oracle(ctx, log_n, cols, pad):
+    """One commit per column of a strided batch (the per-register loop of stark.rs:293-306) equals
+    the single-column commit of every column."""
+    import torch
+    n = 1 << log_n
+    stride = n + pad
+    host = _edge_vector(cols * stride, 900 + log_n).reshape(cols, stride, 2)
+    dev = torch.from_numpy(host.view(np.int64)).cuda()
+    roots = ctx.merkle_roots_fe_batch_dev(dev, n, cols, stride)
+    assert len(roots) == cols
+    for c in range(cols):
+        assert roots[c] == oc.merkle_commit_fe(np.ascontiguousarray(host[c, :n]))
+
+
+def test_merkle_roots_batch_errors(ctx):
+    import torch
+    from stark_amd import StarkError
+    dev = torch.zeros((4, 8, 2), dtype=torch.int64).cuda()
+    with pytest.raises(StarkError, match="power of two"):
+        ctx.merkle_roots_fe_batch_dev(dev, 6, 2, 8)
+    with pytest.raises(StarkError, match="stride"):
+        ctx.merkle_roots_fe_batch_dev(dev, 8, 2, 4)
+    assert ctx.merkle_roots_fe_batch_dev(dev, 8, 0, 8) == []
+
+
 # ---- FRI (fri.rs) -------------------------------------------------------------------
 @pytest.mark.parametrize("log_n", [1, 2, 8, 9, 13, 18])
 def test_fri_fold_vs_oracle(ctx, log_n):
