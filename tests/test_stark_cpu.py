@@ -79,7 +79,7 @@ def test_mpolynomial_evaluate():
     e1, e2, e3 = m1.eval(point), m2.eval(point), m3.eval(point)
     assert so.fe_mul(e1, e2) == e3
     assert so.fe_add(e1, e2) == (m1 + m2).eval(point)
-    assert e1 == 10 + 625 and e2 == 45
+    assert (e1, e2, e3) == (635, 45, 28575)                     # the literal values of :264-266
 
 
 def test_mpolynomial_lift_and_symbolic(ref_kats):
@@ -259,3 +259,44 @@ def test_proof_file_roundtrip(hm, rescue_proof, tmp_path):
     objs = so.ProofStream.deserialize(back).objects
     assert hm.Stream.deserialize(back).objects == objs
     assert hm.Stream.from_objects(objs).serialize() == proof
+
+
+def test_reference_polynomial_known_answers(hm):
+    """The literal cases of the reference's own unit tests (univariate_poly.rs:508-817), on the
+    restatement and on the C++ mirror."""
+    ev = so.poly_eval
+    cases = [
+        # (op, a, b, expected)                                                     reference test
+        (0, [10, 3, 1], [90, 3, 1], [100, 6, 2]),                                   # test_add_same_degree
+        (1, [80, 6, 1], [40, 3, 6], [40, 3, P - 5]),                                # test_sub_same_degree
+        (1, [80, 6, 1, 80, 6, 1], [40, 3, 6], [80, 6, 1, 40, 3, P - 5]),            # test_sub_larger_lhs
+        (1, [40, 3, 6], [80, 6, 1, 80, 6, 1], [P - 80, P - 6, P - 1, P - 40, P - 3, 5]),   # test_sub_larger_rhs
+        (0, [10, 3, 1], [1, 2, 3, 90, 3, 1], [1, 2, 3, 100, 6, 2]),                 # test_add_diff_degree
+        (3, [1, 3, 2], [1, 2], [1, 1]),                                             # test_div_1: (x+2)(x+1) / (x+2)
+        (3, [1, 3, 2], [1, 1], [1, 2]),
+    ]
+    fn = {0: sp.poly_add, 1: sp.poly_sub, 2: sp.poly_mul, 3: sp.poly_div}
+    for op, a, b, want in cases:
+        assert fn[op](a, b) == want
+        assert _poly_op(hm, op, a, b) == want
+    prod = sp.poly_mul([10, 1, 0, 1], [3, 1, 17])                                   # test_mul
+    assert ev(prod, 2) == 2635 and _poly_op(hm, 2, [10, 1, 0, 1], [3, 1, 17]) == prod
+    assert ev(sp.poly_neg([10, 3, 1]), 9) == P - 838                                # test_negate
+    assert _poly_op(hm, 7, [10, 3, 1], []) == sp.poly_neg([10, 3, 1])
+    assert ev([10, 3, 1], 2) == 47                                                  # test_eval
+    assert ev([1, 0], 2) == 2 and ev([3, 5], 2) == 11 and ev([1, 2, 3], 2) == 11    # test_polynomial_coefficient_order
+    # test_distributivity
+    a, b, c = [0, 1, 2], [2, 2, 1], [0, 5, 2, 5, 5, 1]
+    assert sp.poly_mul(a, sp.poly_add(b, c)) == sp.poly_add(sp.poly_mul(a, b), sp.poly_mul(a, c))
+    # test_div_2: (x^6 + 20x^5 + 35x^4 - 1460x^3 - 9396x^2 - 12960x) / (x^2 - 7x - 18), with the
+    # reference's negative literals mapped into the field
+    num = [so.fe_new(v) for v in (1, 20, 35, -1460, -9396, -12960, 0)]
+    den = [so.fe_new(v) for v in (1, -7, -18)]
+    q = sp.poly_div(num, den)
+    assert q == _poly_op(hm, 3, num, den) and len(q) == 5
+    assert sp.poly_mul(q, den) == num                                               # the division is exact
+    # test_polynomial_division_consistency: quotient * divisor + remainder = dividend
+    q = sp.poly_div([3, 2, 1], [1, 1])
+    rem = sp.poly_sub([3, 2, 1], sp.poly_mul(q, [1, 1]))
+    assert sp.poly_add(sp.poly_mul(q, [1, 1]), rem) == [3, 2, 1] and q == [3, P - 1]
+    assert so.test_colinearity([(0, 0), (1, 1), (2, 2)])                            # test_test_colinearity
