@@ -241,9 +241,11 @@ __device__ __forceinline__ void round1_exchange(fe5 (&v)[16], fe5* lds, const tw
 #pragma clang loop unroll(full)
     for (int ph = 0; ph < 2; ph++) {
         if (ph > 0) lds_barrier();          // phase 0 fully read before it is overwritten
+        int tw_ = t;                        // LDS addresses are formed per phase rather than kept in registers
+        asm volatile("" : "+v"(tw_));
 #pragma clang loop unroll(full)
         for (int g = 0; g < G::G1; g++) {
-            const int q1 = t + TILE_THREADS * g;
+            const int q1 = tw_ + TILE_THREADS * g;
             int jb, c;
             if constexpr (MODE == PASS_LAST) { c = q1 >> 4; jb = q1 & 15; }
             else { jb = q1 >> G::LOGC; c = q1 & (G::C - 1); }
