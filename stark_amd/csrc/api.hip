@@ -898,12 +898,13 @@ static int32_t fri_commit_impl(stark_ctx* ctx, const fe* cw_src, bool src_is_hos
     rc = fold_tables(ctx, om, N / 2, &pt);
     if (rc != STARK_OK) return cleanup(rc);
 
-    FRI_HIP(hipMemcpyAsync(L->cw[0], cw_src, N * sizeof(fe),
-                           src_is_host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, ctx->stream));   // fri.rs:130
+    if (src_is_host)                                                                                   // fri.rs:130
+        FRI_HIP(hipMemcpyAsync(L->cw[0], cw_src, N * sizeof(fe), hipMemcpyHostToDevice, ctx->stream));
     // Roots arrive through host-mapped pinned memory, written by the kernel that
     // produces them; a one-leaf layer has no such kernel and is copied instead.
     digest* root_mail = (digest*)((uint8_t*)ctx->pinned + 2048);
-    FRI_HIP(launch_leaf_hash(L->cw[0], L->tree[0], N, ctx->stream));
+    if (src_is_host) FRI_HIP(launch_leaf_hash(L->cw[0], L->tree[0], N, ctx->stream));
+    else FRI_HIP(launch_leaf_hash_copy(cw_src, L->cw[0], L->tree[0], N, ctx->stream));   // device source: copy in the hash pass
     FRI_HIP(launch_merkle_reduce(L->tree[0], N, ctx->stream, root_mail));                                  // fri.rs:119
     // 2^-1 alpha offset_r^-1 per round: the two inverses are taken once (a Fermat inverse is ~400
     // host multiplications) and offset_r^-1 = (offset^-1)^(2^r) follows by squaring (fri.rs:142)

@@ -44,6 +44,24 @@ hipError_t launch_leaf_hash_batch(const fe* elems, size_t col_stride, digest* le
     return hipGetLastError();
 }
 
+// Leaf digests of a vector that is also copied on the way (the first layer of a FRI commit keeps
+// its own copy of the codeword, fri.rs:130): the kernel is bound by the hash, the store is free.
+__global__ __launch_bounds__(256) void leaf_hash_copy_kernel(const fe* __restrict__ elems, fe* __restrict__ copy,
+                                                             digest* __restrict__ out, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    fe x = elems[i];
+    copy[i] = x;
+    out[i] = leaf_digest(x.lo, x.hi);
+}
+
+hipError_t launch_leaf_hash_copy(const fe* elems, fe* copy, digest* level0, size_t n, hipStream_t s)
+{
+    hipLaunchKernelGGL(leaf_hash_copy_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, elems, copy, level0, n);
+    return hipGetLastError();
+}
+
 hipError_t launch_leaf_hash(const fe* elems, digest* level0, size_t n, hipStream_t s)
 {
     hipLaunchKernelGGL(leaf_hash_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, elems, level0, n);

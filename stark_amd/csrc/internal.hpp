@@ -74,6 +74,7 @@ hipError_t launch_vec_mul(const fe* a, const fe* b, fe* out, size_t n, fe r2, hi
 // Tree storage: levels concatenated, leaf digests first; level l holds n>>l
 // digests at digest offset 2n - (2n >> l); the root is digest 2n-2.
 hipError_t launch_leaf_hash(const fe* elems, digest* level0, size_t n, hipStream_t s);
+hipError_t launch_leaf_hash_copy(const fe* elems, fe* copy, digest* level0, size_t n, hipStream_t s);
 hipError_t launch_leaf_hash_bytes(const uint8_t* flat, const uint64_t* offsets, digest* level0, size_t n,
                                   hipStream_t s);
 // Reduce a level of m digests (power of two) to the root, writing every level
