@@ -256,6 +256,35 @@ def main():
             multi["lde_commit_64x2^20_to_2^22_ms"] = round(ms, 3)
             multi["lde_commit_Melem_s_out"] = round((64 << 22) / ms / 1e3, 1)
             del cl
+            # FRI commit of one 2^24 codeword dealt out in chunks over the ranks (folds and hashing
+            # local, 32-byte subtree roots all-gathered per round, the small layers on every rank)
+            if world & (world - 1) == 0:
+                import hashlib
+                from stark_amd.distributed import fri_commit_sharded
+                n24 = 1 << 24
+                w24 = pow(GENERATOR, (1 << 119) >> 24, (407 << 119) + 1)      # primitive_nth_root(2^24)
+                share = torch.from_numpy(field_vector(n24 // world, 3000 + rank).view(np.int64)).to(dev)
+
+                def fri_sharded_once():
+                    objs = []
+
+                    def transcript(rnd, last, root):
+                        objs.append(root.hex())
+                        if last:
+                            return None
+                        ser = len(objs).to_bytes(8, "little") + b"".join(
+                            len(o).to_bytes(8, "little") + o.encode() for o in objs)
+                        return int.from_bytes(hashlib.shake_256(ser).digest(32), "big") % ((407 << 119) + 1)
+                    fri_commit_sharded(eng, share, n24, GENERATOR, w24, 4, 17, transcript).tail.free()
+
+                fri_sharded_once()
+                barrier()
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    fri_sharded_once()
+                barrier()
+                multi["fri_commit_2^24_sharded_ms"] = round((time.perf_counter() - t0) / 3 * 1e3, 3)
+                del share
             if world > 1:
                 n24 = 1 << 24
                 per = n24 // world

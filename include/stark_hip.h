@@ -119,6 +119,17 @@ int32_t stark_merkle_commit_fe_dev(stark_ctx* ctx, const uint64_t* elems_dev, si
  * (host).  All columns go through the same launches; trees are not retained. */
 int32_t stark_merkle_roots_fe_batch_dev(stark_ctx* ctx, const uint64_t* elems_dev, size_t n, size_t n_cols,
                                         size_t col_stride, uint8_t* roots_out);
+/* A Merkle tree cut across devices.  Merkle::commit pairs nodes (2i, 2i+1)
+ * level by level (merkle.rs:38-51), so every aligned run of chunk_len leaves
+ * (a power of two) is a subtree of its own: a device that holds n_chunks such
+ * runs back to back at elems_dev reduces each to its subtree root here
+ * (roots_dev_out: n_chunks x 32 bytes of device memory, not synchronised), and
+ * stark_merkle_root_of_digests_dev finishes the tree from all m subtree roots
+ * in leaf order (device memory, m a power of two; root is host memory).  The
+ * root equals Merkle::commit over all the leaves. */
+int32_t stark_merkle_subtree_roots_dev(stark_ctx* ctx, const uint64_t* elems_dev, size_t chunk_len,
+                                       size_t n_chunks, uint8_t* roots_dev_out);
+int32_t stark_merkle_root_of_digests_dev(stark_ctx* ctx, const uint8_t* digests_dev, size_t m, uint8_t root[32]);
 /* Merkle::commit(&Vec<Vec<u8>>) for arbitrary byte leaves: leaf i is
  * flat[offsets[i] .. offsets[i+1]) (host pointers). */
 int32_t stark_merkle_commit_bytes(stark_ctx* ctx, const uint8_t* flat, const uint64_t* offsets, size_t n,
@@ -138,6 +149,21 @@ int32_t stark_fri_fold(stark_ctx* ctx, const uint64_t* codeword, size_t N, const
                        const uint64_t offset[2], const uint64_t omega[2], uint64_t* out);
 int32_t stark_fri_fold_dev(stark_ctx* ctx, const uint64_t* codeword_dev, size_t N, const uint64_t alpha[2],
                            const uint64_t offset[2], const uint64_t omega[2], uint64_t* out_dev);
+
+/* The same fold (fri.rs:133-138) on one device's share of a layer of length N
+ * that is dealt out in chunks: the share is the chunks [q*period + base,
+ * q*period + base + chunk_len), q = 0 .. N/period - 1, back to back
+ * (local_len = N/period * chunk_len elements; chunk_len, period powers of two,
+ * period <= N/2 so that positions i and N/2+i lie in the same share).  out_dev
+ * receives the share of the folded layer in the same arrangement (local_len/2
+ * elements); omega and offset are those of the layer being folded.  If
+ * chunk_roots_dev_out is not NULL it receives the subtree root of every output
+ * chunk (local_len/2/chunk_len x 32 bytes, device memory), as
+ * stark_merkle_subtree_roots_dev would compute them.  Not synchronised. */
+int32_t stark_fri_fold_shard_dev(stark_ctx* ctx, const uint64_t* local_dev, size_t local_len,
+                                 const uint64_t alpha[2], const uint64_t offset[2], const uint64_t omega[2],
+                                 size_t chunk_len, size_t period, size_t base, uint64_t* out_dev,
+                                 uint8_t* chunk_roots_dev_out);
 
 /* Fri::num_rounds (fri.rs:39-51). */
 size_t stark_fri_num_rounds(size_t domain_length, size_t expansion_factor, size_t num_colinearity_tests);

@@ -43,6 +43,8 @@ SIGNATURES = {
     "stark_merkle_commit_fe": (i32, [C.c_void_p, C.c_void_p, sz, u8p, voidpp]),
     "stark_merkle_commit_fe_dev": (i32, [C.c_void_p, C.c_void_p, sz, u8p, voidpp]),
     "stark_merkle_roots_fe_batch_dev": (i32, [C.c_void_p, C.c_void_p, sz, sz, sz, C.c_void_p]),
+    "stark_merkle_subtree_roots_dev": (i32, [C.c_void_p, C.c_void_p, sz, sz, C.c_void_p]),
+    "stark_merkle_root_of_digests_dev": (i32, [C.c_void_p, C.c_void_p, sz, u8p]),
     "stark_merkle_commit_bytes": (i32, [C.c_void_p, C.c_void_p, C.c_void_p, sz, u8p, voidpp]),
     "stark_merkle_open": (i32, [C.c_void_p, sz, u8p, szp]),
     "stark_tree_num_leaves": (sz, [C.c_void_p]),
@@ -50,6 +52,8 @@ SIGNATURES = {
     "stark_tree_free": (None, [C.c_void_p]),
     "stark_fri_fold": (i32, [C.c_void_p, C.c_void_p, sz, u64p, u64p, u64p, C.c_void_p]),
     "stark_fri_fold_dev": (i32, [C.c_void_p, C.c_void_p, sz, u64p, u64p, u64p, C.c_void_p]),
+    "stark_fri_fold_shard_dev": (i32, [C.c_void_p, C.c_void_p, sz, u64p, u64p, u64p, sz, sz, sz, C.c_void_p,
+                                       C.c_void_p]),
     "stark_fri_num_rounds": (sz, [sz, sz, sz]),
     "stark_fri_commit": (i32, [C.c_void_p, C.c_void_p, sz, u64p, u64p, sz, sz, TRANSCRIPT_CB, C.c_void_p, voidpp]),
     "stark_fri_commit_dev": (i32, [C.c_void_p, C.c_void_p, sz, u64p, u64p, sz, sz, TRANSCRIPT_CB, C.c_void_p, voidpp]),
@@ -65,6 +69,25 @@ SIGNATURES = {
 _lib = None
 
 
+def preload_hip_runtime() -> None:
+    """A process must hold ONE HIP runtime.  A PyTorch-ROCm wheel carries its own
+    libamdhip64.so (and HSA runtime) and asks for it by a name that does not
+    match the soname of the system copy, so if this library pulled the system
+    copy in first, a later torch.cuda initialisation would start a second
+    runtime and find "No HIP GPUs".  When such a wheel is installed, load its
+    copy first; libstark_hip.so's dependency then resolves to it by soname."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    bundled = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(bundled):
+        C.CDLL(bundled, mode=C.RTLD_GLOBAL)
+
+
 def load() -> C.CDLL:
     """Returns the loaded library; raises if it has not been built."""
     global _lib
@@ -74,6 +97,7 @@ def load() -> C.CDLL:
         raise RuntimeError(
             f"{LIB_PATH} not found: build it with `make -C stark_amd/csrc` "
             "(or python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback.")
+    preload_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is missing

@@ -408,8 +408,8 @@ static int32_t tree_build(stark_ctx* ctx, const fe* elems_dev, size_t n, uint8_t
     return STARK_OK;
 }
 
-extern "C" int32_t stark_merkle_roots_fe_batch_dev(stark_ctx* ctx, const uint64_t* elems_dev, size_t n, size_t n_cols,
-                                                   size_t col_stride, uint8_t* roots_out)
+static int32_t roots_batch(stark_ctx* ctx, const uint64_t* elems_dev, size_t n, size_t n_cols, size_t col_stride,
+                           uint8_t* roots_out, bool out_is_device)
 {
     if (!ctx || !elems_dev || !roots_out) return fail(STARK_EARG, "null argument");
     const int log_n = log2_exact(n);
@@ -430,9 +430,39 @@ extern "C" int32_t stark_merkle_roots_fe_batch_dev(stark_ctx* ctx, const uint64_
         HIP_TRY(launch_leaf_hash_batch((const fe*)elems_dev + c0 * col_stride, col_stride, level0, (uint32_t)log_n, g,
                                        ctx->stream));
         HIP_TRY(launch_merkle_reduce(level0, g * n, ctx->stream, nullptr, g, &roots_dev));
-        HIP_TRY(hipMemcpyAsync(roots_out + 32 * c0, roots_dev, 32 * g, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        HIP_TRY(hipMemcpyAsync(roots_out + 32 * c0, roots_dev, 32 * g,
+                               out_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
+        if (!out_is_device) HIP_TRY(hipStreamSynchronize(ctx->stream));
     }
+    return STARK_OK;
+}
+
+extern "C" int32_t stark_merkle_roots_fe_batch_dev(stark_ctx* ctx, const uint64_t* elems_dev, size_t n, size_t n_cols,
+                                                   size_t col_stride, uint8_t* roots_out)
+{
+    return roots_batch(ctx, elems_dev, n, n_cols, col_stride, roots_out, false);
+}
+
+extern "C" int32_t stark_merkle_subtree_roots_dev(stark_ctx* ctx, const uint64_t* elems_dev, size_t chunk_len,
+                                                  size_t n_chunks, uint8_t* roots_dev_out)
+{
+    return roots_batch(ctx, elems_dev, chunk_len, n_chunks, chunk_len, roots_dev_out, true);
+}
+
+extern "C" int32_t stark_merkle_root_of_digests_dev(stark_ctx* ctx, const uint8_t* digests_dev, size_t m,
+                                                    uint8_t root[32])
+{
+    if (!ctx || !digests_dev || !root) return fail(STARK_EARG, "null argument");
+    if (log2_exact(m) < 0) return fail(STARK_ENOTPOW2, "length must be power of two");
+    // the reduction writes every level behind the one it reads: work on a copy with room for them
+    DevBuf levels(ctx);
+    ST_TRY(levels.alloc((2 * m - 1) * sizeof(digest)));
+    HIP_TRY(hipMemcpyAsync(levels.p, digests_dev, m * sizeof(digest), hipMemcpyDeviceToDevice, ctx->stream));
+    digest* top = nullptr;
+    HIP_TRY(launch_merkle_reduce((digest*)levels.p, m, ctx->stream, nullptr, 1, &top));
+    HIP_TRY(hipMemcpyAsync(ctx->pinned, top, sizeof(digest), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    memcpy(root, ctx->pinned, 32);
     return STARK_OK;
 }
 
@@ -817,6 +847,52 @@ extern "C" int32_t stark_fri_fold_dev(stark_ctx* ctx, const uint64_t* codeword_d
     a.half = N / 2;
     a.shift = 0;
     HIP_TRY(launch_fri_fold(a, ctx->stream));
+    return STARK_OK;
+}
+
+extern "C" int32_t stark_fri_fold_shard_dev(stark_ctx* ctx, const uint64_t* local_dev, size_t local_len,
+                                            const uint64_t alpha[2], const uint64_t offset[2], const uint64_t omega[2],
+                                            size_t chunk_len, size_t period, size_t base, uint64_t* out_dev,
+                                            uint8_t* chunk_roots_dev_out)
+{
+    if (!ctx || !local_dev || !alpha || !offset || !omega || !out_dev) return fail(STARK_EARG, "null argument");
+    const int log_chunk = log2_exact(chunk_len), log_period = log2_exact(period);
+    if (log_chunk < 0 || log_period < 0) return fail(STARK_ENOTPOW2, "chunk length and period must be powers of two");
+    if (chunk_len > period || base % chunk_len != 0 || base + chunk_len > period)
+        return fail(STARK_EARG, "chunk does not lie inside one period");
+    // the partner of position i is i + (layer length)/2: it is local only if the local share is a
+    // whole, even number of chunks
+    if (local_len == 0 || local_len % (2 * chunk_len) != 0)
+        return fail(STARK_ELENGTH, "local share must be an even number of chunks");
+    fe al{alpha[0], alpha[1]}, of{offset[0], offset[1]}, om{omega[0], omega[1]};
+    if (!is_canonical(al) || !is_canonical(of) || !is_canonical(om)) return fail(STARK_EARG, "scalar not reduced modulo p");
+    const size_t half = local_len / 2, chunks_out = half / chunk_len;
+    const PowTables* pt;
+    ST_TRY(fold_tables(ctx, om, chunks_out * period, &pt));     // positions of the outputs are < (layer length)/2
+    FoldArgs a{};
+    a.cw = (const fe*)local_dev;
+    a.out = (fe*)out_dev;
+    a.leaf_out = nullptr;
+    a.hi = (const fe*)pt->hi;
+    a.lo = (const fe*)pt->lo;
+    a.c_m = fold_constant(ctx->F, al, of);
+    a.half = half;
+    a.shift = 0;
+    a.log_chunk = (uint32_t)log_chunk;
+    a.log_period = (uint32_t)log_period;
+    a.base = base;
+    if (!chunk_roots_dev_out) {
+        HIP_TRY(launch_fri_fold(a, ctx->stream));
+        return STARK_OK;
+    }
+    // leaf digests of the outputs in the same pass, then one subtree per output chunk
+    DevBuf trees(ctx);
+    ST_TRY(trees.alloc((2 * half - 1) * sizeof(digest)));
+    a.leaf_out = (digest*)trees.p;
+    HIP_TRY(launch_fri_fold(a, ctx->stream));
+    digest* roots = nullptr;
+    HIP_TRY(launch_merkle_reduce(a.leaf_out, half, ctx->stream, nullptr, chunks_out, &roots));
+    HIP_TRY(hipMemcpyAsync(chunk_roots_dev_out, roots, chunks_out * sizeof(digest), hipMemcpyDeviceToDevice, ctx->stream));
     return STARK_OK;
 }
 

@@ -348,7 +348,8 @@ __device__ __forceinline__ fe fold_one(const FoldArgs& a, size_t i)
     fe x = a.cw[i], y = a.cw[a.half + i];
     fe sum = fe_half(fe_add(x, y));
     fe dif = fe_sub(x, y);
-    const uint64_t E = (uint64_t)i << a.shift;
+    const uint64_t pos = (((uint64_t)i >> a.log_chunk) << a.log_period) + a.base + ((uint64_t)i & ((1ull << a.log_chunk) - 1));
+    const uint64_t E = pos << a.shift;
     fe w = a.hi[E >> 8];
     const uint32_t el = (uint32_t)(E & 255);
     if (el) w = mont_mul(w, a.lo[el]);

@@ -95,6 +95,12 @@ struct FoldArgs {
     fe c_m;                // 2^-1 * alpha * offset^-1, Montgomery form
     uint64_t half;         // N/2
     uint32_t shift;        // omega of this layer = w^(2^shift)
+    // Position of local element l in the whole layer: ((l >> log_chunk) << log_period) + base +
+    // (l & (2^log_chunk - 1)).  A device that holds one chunk out of every period of a layer
+    // folds its share with these; the defaults (63, 0, 0) make the position equal to l.
+    uint32_t log_chunk = 63;
+    uint32_t log_period = 0;
+    uint64_t base = 0;
 };
 hipError_t launch_fri_fold(const FoldArgs& a, hipStream_t s);
 hipError_t launch_fri_fold_commit(const FoldArgs& a, hipStream_t s, digest* root_out);

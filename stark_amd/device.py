@@ -223,6 +223,16 @@ class Context:
         raw = bytes(roots)
         return [raw[32 * c:32 * (c + 1)] for c in range(n_cols)]
 
+    def merkle_subtree_roots_dev(self, dptr, chunk_len: int, n_chunks: int, roots_dptr):
+        """Subtree root of each of n_chunks aligned runs of chunk_len leaves, left in device memory."""
+        self._chk(self.lib.stark_merkle_subtree_roots_dev(self.h, _ptr(dptr), chunk_len, n_chunks, _ptr(roots_dptr)))
+
+    def merkle_root_of_digests_dev(self, dptr, m: int) -> bytes:
+        """Root of the tree whose lowest level is the m digests at dptr (device memory)."""
+        root = (C.c_uint8 * 32)()
+        self._chk(self.lib.stark_merkle_root_of_digests_dev(self.h, _ptr(dptr), m, root))
+        return bytes(root)
+
     def merkle_commit_bytes(self, leaves: Sequence[bytes], keep_tree: bool = False):
         flat = np.frombuffer(b"".join(leaves) or b"\0", dtype=np.uint8).copy()
         offs = np.zeros(len(leaves) + 1, dtype=np.uint64)
@@ -245,6 +255,12 @@ class Context:
     def fri_fold_dev(self, cw_ptr, n: int, alpha: int, offset: int, omega: int, out_ptr):
         self._chk(self.lib.stark_fri_fold_dev(self.h, _ptr(cw_ptr), n, _fe(alpha), _fe(offset), _fe(omega),
                                               _ptr(out_ptr)))
+
+    def fri_fold_shard_dev(self, local_ptr, local_len: int, alpha: int, offset: int, omega: int, chunk_len: int,
+                           period: int, base: int, out_ptr, chunk_roots_ptr=None):
+        self._chk(self.lib.stark_fri_fold_shard_dev(self.h, _ptr(local_ptr), local_len, _fe(alpha), _fe(offset),
+                                                    _fe(omega), chunk_len, period, base, _ptr(out_ptr),
+                                                    None if chunk_roots_ptr is None else _ptr(chunk_roots_ptr)))
 
     def fri_num_rounds(self, domain_length: int, expansion_factor: int, num_colinearity_tests: int) -> int:
         return self.lib.stark_fri_num_rounds(domain_length, expansion_factor, num_colinearity_tests)

@@ -5,6 +5,12 @@
   commitments, stark.rs:293-306 generalised) shard with NO data-path
   collective: column c goes to rank c mod G; only the 32-byte roots are
   gathered.
+* The commit phase of FRI (fri.rs:100-152) on one large codeword deals every
+  layer out in chunks so that position i and its fold partner i + N/2 live on
+  the same rank: folds and leaf hashing are local, each rank reduces its chunks
+  to subtree roots, and only those 32-byte roots are all-gathered per round.
+  Once a layer is down to one chunk per rank it is all-gathered whole and the
+  remaining (latency-bound) rounds run on every rank alike.
 * One transform too large or too slow for one GPU uses a four-step
   decomposition n = n1 * n2 whose transposes are all-to-all exchanges.  The
   reference has no distributed code; the composition below equals
@@ -50,6 +56,29 @@ class HipEngine:
         """Roots of all columns of a contiguous (cols, n, 2) batch in one call."""
         cols, n, _ = columns.shape
         return self.ctx.merkle_roots_fe_batch_dev(columns, n, cols, n)
+
+    # ---- sharded FRI commit ------------------------------------------------
+    def subtree_roots(self, local: torch.Tensor, chunk_len: int) -> torch.Tensor:
+        n_chunks = local.shape[0] // chunk_len
+        roots = torch.empty((n_chunks, 32), dtype=torch.uint8, device=local.device)
+        self.ctx.merkle_subtree_roots_dev(local, chunk_len, n_chunks, roots)
+        return roots
+
+    def root_of_digests(self, digests: torch.Tensor) -> bytes:
+        return self.ctx.merkle_root_of_digests_dev(digests, digests.shape[0])
+
+    def fold_shard(self, local: torch.Tensor, alpha: int, offset: int, omega: int, chunk_len: int, period: int,
+                   base: int, want_roots: bool):
+        half = local.shape[0] // 2
+        out = torch.empty((half, 2), dtype=local.dtype, device=local.device)
+        roots = torch.empty((half // chunk_len, 32), dtype=torch.uint8, device=local.device) if want_roots else None
+        self.ctx.fri_fold_shard_dev(local, local.shape[0], alpha, offset, omega, chunk_len, period, base, out, roots)
+        return out, roots
+
+    def fri_commit(self, codeword: torch.Tensor, offset: int, omega: int, expansion_factor: int,
+                   num_colinearity_tests: int, transcript):
+        return self.ctx.fri_commit(codeword, offset, omega, expansion_factor, num_colinearity_tests, transcript,
+                                   n=codeword.shape[0])
 
 
 # ---------------------------------------------------------------------------
@@ -147,3 +176,119 @@ def fourstep_ntt(x_local: torch.Tensor, n: int, engine, inverse: bool = False, n
         return t
     t = _a2a_transpose(t, group)                                          # [k2_local][k1]
     return t.reshape(n // world, 2)
+
+
+# ---------------------------------------------------------------------------
+# FRI commit phase across ranks
+# ---------------------------------------------------------------------------
+P = 407 * (1 << 119) + 1          # field.rs:32
+
+
+def fri_num_rounds(domain_length: int, expansion_factor: int, num_colinearity_tests: int) -> int:
+    """Fri::num_rounds (fri.rs:39-51)."""
+    length, rounds = domain_length, 0
+    while length > expansion_factor and 4 * num_colinearity_tests < length:
+        length //= 2
+        rounds += 1
+    return rounds
+
+
+def fri_shard_period(n: int, world: int, expansion_factor: int, num_colinearity_tests: int,
+                     period: Optional[int] = None) -> int:
+    """The period of the chunked layout: layers longer than it are folded
+    shard-wise.  At least one chunk element per rank, at most n, and never so
+    small that a sharded fold would be the last round's."""
+    rounds = fri_num_rounds(n, expansion_factor, num_colinearity_tests)
+    if rounds < 1:
+        raise ValueError("Cannot do FRI with less than 1 round")
+    if period is None:
+        period = 1 << 17
+    period = max(period, world, n >> (rounds - 1))
+    return min(period, n)
+
+
+def fri_shard_of(codeword: torch.Tensor, rank: int, world: int, period: int) -> torch.Tensor:
+    """This rank's share of a whole layer (n, 2): chunk `rank` of every period,
+    back to back; local element q*C + j is position q*period + rank*C + j,
+    C = period / world."""
+    n = codeword.shape[0]
+    c = period // world
+    return codeword.view(n // period, world, c, 2)[:, rank].reshape(n // period * c, 2).contiguous()
+
+
+def _all_gather(t: torch.Tensor, group) -> torch.Tensor:
+    """(world, *t.shape), on t's device; through the host when the group's backend cannot take device tensors."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return t.unsqueeze(0)
+    src = t.contiguous()
+    if src.is_cuda and dist.get_backend(group) != "nccl":
+        src = src.cpu()
+    out = [torch.empty_like(src) for _ in range(world)]
+    dist.all_gather(out, src, group=group)
+    return torch.stack(out).to(t.device)
+
+
+class ShardedFriCommit:
+    """Result of fri_commit_sharded: `roots` of all rounds; `shares[k]`, this
+    rank's share of layer k for the layers folded shard-wise; `tail`, the
+    engine's own commit object for the layers from `len(shares)` on, whole on
+    every rank."""
+
+    def __init__(self, roots, shares, tail, period, chunk_len):
+        self.roots: List[bytes] = roots
+        self.shares: List[torch.Tensor] = shares
+        self.tail = tail
+        self.period = period
+        self.chunk_len = chunk_len
+
+    def gather_layer(self, k: int, group=None) -> torch.Tensor:
+        """Layer k < len(shares) in natural order on every rank."""
+        g = _all_gather(self.shares[k], group)                          # [rank][q][j]
+        world = g.shape[0]
+        return g.view(world, -1, self.chunk_len, 2).permute(1, 0, 2, 3).reshape(-1, 2)
+
+
+def fri_commit_sharded(engine, local: torch.Tensor, n: int, offset: int, omega: int, expansion_factor: int,
+                       num_colinearity_tests: int, transcript, period: Optional[int] = None,
+                       group=None) -> ShardedFriCommit:
+    """Fri::commit (fri.rs:100-152) of a length-n codeword of which this rank
+    holds `local` = fri_shard_of(codeword, rank, world, period).
+
+    transcript(round, last, root) -> alpha is called on EVERY rank with the same
+    arguments (each rank keeps its own copy of the proof stream; the roots are
+    identical, so the challenges agree without a broadcast).  Per sharded round
+    the only exchange is an all-gather of 32 bytes per local chunk."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if n < 1 or n & (n - 1):
+        raise ValueError("length must be power of two")
+    if world & (world - 1):
+        raise ValueError("the chunked layout needs a power-of-two number of ranks")
+    period = fri_shard_period(n, world, expansion_factor, num_colinearity_tests, period)
+    if period & (period - 1) or period % world:
+        raise ValueError("period must be a power of two and a multiple of the number of ranks")
+    c = period // world
+    if local.shape != (n // period * c, 2):
+        raise ValueError("local share does not match the chunked layout")
+    sharded_rounds = (n // period).bit_length() - 1
+
+    roots: List[bytes] = []
+    shares: List[torch.Tensor] = []
+    om, of = omega % P, offset % P
+    chunk_roots = engine.subtree_roots(local, c) if sharded_rounds else None
+    for k in range(sharded_rounds):
+        g = _all_gather(chunk_roots, group)                             # [rank][q]; chunk q*world + rank of the layer
+        digests = g.permute(1, 0, 2).reshape(-1, 32).contiguous()
+        root = engine.root_of_digests(digests)                          # fri.rs:119
+        roots.append(root)
+        alpha = transcript(k, False, root)                              # fri.rs:120,126-127
+        shares.append(local)
+        local, chunk_roots = engine.fold_shard(local, alpha, of, om, c, period, rank * c,
+                                               want_roots=k + 1 < sharded_rounds)   # fri.rs:133-139
+        om, of = om * om % P, of * of % P                               # fri.rs:141-142
+    whole = _all_gather(local, group).reshape(period, 2)                # one chunk per rank: the layer in order
+    tail = engine.fri_commit(whole, of, om, expansion_factor, num_colinearity_tests,
+                             lambda r, last, root: transcript(sharded_rounds + r, last, root))
+    roots.extend(tail.root(i) for i in range(len(tail)))
+    return ShardedFriCommit(roots, shares, tail, period, c)

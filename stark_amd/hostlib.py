@@ -12,6 +12,9 @@ PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "host", "libstar
 if not os.path.exists(PATH):
     raise ImportError(f"{PATH} is missing: build it with `make -C stark_amd/host` (needs libstark_hip.so first)")
 
+from ._lib import preload_hip_runtime  # noqa: E402
+
+preload_hip_runtime()
 lib = C.CDLL(PATH)
 lib.sh_last_panic.restype = C.c_char_p
 lib.sh_ps_new.restype = C.c_void_p

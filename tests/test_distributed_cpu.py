@@ -54,6 +54,115 @@ class OracleEngine:
     def merkle_root(self, column):
         return self.oc.merkle_commit_fe(np.ascontiguousarray(column.numpy().view(np.uint64)))
 
+    # ---- sharded FRI commit ------------------------------------------------
+    def subtree_roots(self, local, chunk_len):
+        a = local.numpy().view(np.uint64)
+        roots = [self.oc.merkle_commit_fe(np.ascontiguousarray(a[i:i + chunk_len]))
+                 for i in range(0, a.shape[0], chunk_len)]
+        return torch.from_numpy(np.frombuffer(b"".join(roots), dtype=np.uint8).reshape(-1, 32).copy())
+
+    def root_of_digests(self, digests):
+        level = [bytes(d.tolist()) for d in digests]
+        while len(level) > 1:                                  # merkle.rs:38-51 pairs (2i, 2i+1)
+            level = [self.oc.blake2b(level[i] + level[i + 1]) for i in range(0, len(level), 2)]
+        return level[0]
+
+    def fold_shard(self, local, alpha, offset, omega, chunk_len, period, base, want_roots):
+        so, oc = self.so, self.oc
+        a = oc.to_ints(local.numpy().view(np.uint64))
+        half = len(a) // 2
+        two_inv = so.fe_inverse(2)
+        out = []
+        for l in range(half):                                  # fri.rs:133-138 at the element's position in the layer
+            pos = (l // chunk_len) * period + base + l % chunk_len
+            r = so.fe_div(alpha, so.fe_mul(offset, so.fe_pow(omega, pos)))
+            out.append(so.fe_mul(two_inv, so.fe_add(so.fe_mul(so.fe_add(1, r), a[l]),
+                                                    so.fe_mul(so.fe_sub(1, r), a[half + l]))))
+        t = torch.from_numpy(oc.from_ints(out).view(np.int64))
+        return t, (self.subtree_roots(t, chunk_len) if want_roots else None)
+
+    def fri_commit(self, codeword, offset, omega, expansion, ncol, transcript):
+        so, oc = self.so, self.oc
+        cw = np.ascontiguousarray(codeword.numpy().view(np.uint64))
+        rounds = oc.lib.so_fri_num_rounds(cw.shape[0], expansion, ncol)
+        layers, roots = [], []
+        for r in range(rounds):
+            root = oc.merkle_commit_fe(cw)
+            roots.append(root)
+            layers.append(cw)
+            alpha = transcript(r, r == rounds - 1, root)
+            if r == rounds - 1:
+                break
+            cw = oc.fri_fold(cw, alpha, offset, omega)
+            offset, omega = so.fe_mul(offset, offset), so.fe_mul(omega, omega)
+
+        class Tail:
+            def __len__(self):
+                return len(roots)
+
+            def root(self, i):
+                return roots[i]
+        tail = Tail()
+        tail.layers = layers
+        return tail
+
+
+def _fri_worker(rank, world, port, log_n, period, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sys.path.insert(0, ROOT)
+        from stark_amd import distributed as D
+        eng = OracleEngine()
+        oc, so = eng.oc, eng.so
+        n, expansion, ncol = 1 << log_n, 4, 2
+        x = oc.splitmix(n, 123)
+        omega, offset = so.primitive_nth_root(n), so.GENERATOR
+        ref_layers, ref_roots, ref_alphas, _ = oc.fri_commit(x, offset, omega, expansion, ncol)
+        used = D.fri_shard_period(n, world, expansion, ncol, period)
+        local = D.fri_shard_of(torch.from_numpy(x.view(np.int64)), rank, world, used)
+        stream, alphas = oc.Stream(), []
+
+        def transcript(rnd, last, root):
+            stream.push(root.hex())
+            if last:
+                return None
+            alphas.append(so.fe_sample(stream.fiat_shamir(32)))
+            return alphas[-1]
+
+        res = D.fri_commit_sharded(eng, local, n, offset, omega, expansion, ncol, transcript, period=period)
+        ok = res.roots == ref_roots and alphas == ref_alphas
+        k_sh = len(res.shares)
+        for k in range(k_sh):
+            ok = ok and np.array_equal(res.gather_layer(k).numpy().view(np.uint64), ref_layers[k])
+        for i, lay in enumerate(res.tail.layers):
+            ok = ok and np.array_equal(lay, ref_layers[k_sh + i])
+        ok = ok and k_sh + len(res.tail.layers) == len(ref_layers)
+        q.put((rank, ok, k_sh))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,log_n,period,sharded", [(2, 10, 64, 4), (2, 9, None, 0), (4, 10, 4, 6), (2, 8, 2, 4)])
+def test_fri_commit_sharded_gloo(world, log_n, period, sharded):
+    """Every round's root, every challenge and every layer equal the
+    single-vector commit; `sharded` = rounds folded shard-wise (a period below
+    n >> (rounds-1) is raised to it so the last round is never a sharded one)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000) + world * 11 + log_n
+    procs = [ctx.Process(target=_fri_worker, args=(r, world, port, log_n, period, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok, k_sh in results:
+        assert ok, f"rank {rank}: sharded commit differs from the single-vector commit"
+        assert k_sh == sharded
+
 
 def _worker(rank, world, port, log_n, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"

@@ -81,3 +81,101 @@ def test_column_sharded_lde_commit_single_rank(group, engine):
         ref = oc.coset_lde(coeffs[c], n_out, so.GENERATOR)
         assert np.array_equal(cw[c].cpu().numpy().view(np.uint64), ref)
         assert roots[c] == oc.merkle_commit_fe(ref)
+
+
+def test_fri_commit_sharded_single_rank(group, engine):
+    """One rank, several chunks per period is not possible (chunk = period), but
+    the sharded rounds, the exchange code on device tensors and the hand-over to
+    the whole-layer commit all run; results equal the single-vector commit."""
+    import torch
+    from stark_amd.distributed import fri_commit_sharded
+    n, expansion, ncol = 1 << 16, 4, 17
+    x = oc.splitmix(n, 77)
+    omega, offset = so.primitive_nth_root(n), so.GENERATOR
+    ref_layers, ref_roots, ref_alphas, _ = oc.fri_commit(x, offset, omega, expansion, ncol)
+    stream, alphas = oc.Stream(), []
+
+    def transcript(rnd, last, root):
+        stream.push(root.hex())
+        if last:
+            return None
+        alphas.append(so.fe_sample(stream.fiat_shamir(32)))
+        return alphas[-1]
+
+    res = fri_commit_sharded(engine, torch.from_numpy(x.view(np.int64)).cuda(), n, offset, omega, expansion, ncol,
+                             transcript, period=1 << 10)
+    torch.cuda.synchronize()
+    assert len(res.shares) == 6
+    assert res.roots == ref_roots and alphas == ref_alphas
+    for k in range(len(res.shares)):
+        assert np.array_equal(res.gather_layer(k).cpu().numpy().view(np.uint64), ref_layers[k])
+    for i in range(len(res.tail)):
+        assert np.array_equal(res.tail.download(i), ref_layers[len(res.shares) + i])
+    res.tail.free()
+
+
+def _fri_two_rank_worker(rank, world, port, q):
+    import sys
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        here = os.path.dirname(os.path.abspath(__file__))
+        for p in (os.path.dirname(here), here, os.path.join(os.path.dirname(here), "oracle")):
+            if p not in sys.path:
+                sys.path.insert(0, p)
+        import oracle_c
+        import stark_oracle
+        from stark_amd import Context
+        from stark_amd.distributed import HipEngine, fri_commit_sharded, fri_shard_of, fri_shard_period
+        torch.cuda.set_device(0)
+        ctx = Context(0)
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        eng = HipEngine(ctx)
+        n, expansion, ncol = 1 << 18, 4, 17
+        x = oracle_c.splitmix(n, 78)
+        omega, offset = stark_oracle.primitive_nth_root(n), stark_oracle.GENERATOR
+        ref_layers, ref_roots, ref_alphas, _ = oracle_c.fri_commit(x, offset, omega, expansion, ncol)
+        period = fri_shard_period(n, world, expansion, ncol, 1 << 12)
+        local = fri_shard_of(torch.from_numpy(x.view(np.int64)), rank, world, period).cuda()
+        stream, alphas = oracle_c.Stream(), []
+
+        def transcript(rnd, last, root):
+            stream.push(root.hex())
+            if last:
+                return None
+            alphas.append(stark_oracle.fe_sample(stream.fiat_shamir(32)))
+            return alphas[-1]
+
+        res = fri_commit_sharded(eng, local, n, offset, omega, expansion, ncol, transcript, period=1 << 12)
+        torch.cuda.synchronize()
+        ok = res.roots == ref_roots and alphas == ref_alphas and len(res.shares) == 6
+        for k in range(len(res.shares)):
+            ok = ok and np.array_equal(res.gather_layer(k).cpu().numpy().view(np.uint64), ref_layers[k])
+        for i in range(len(res.tail)):
+            ok = ok and np.array_equal(res.tail.download(i), ref_layers[len(res.shares) + i])
+        res.tail.free()
+        ctx.close()
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_fri_commit_sharded_two_ranks_one_gpu():
+    """Two processes share the one GPU of a test box (each with its own context
+    and HIP kernels; the 32-byte exchanges go through gloo): roots, challenges
+    and layers equal the single-vector commit."""
+    import torch.multiprocessing as mp
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    port = 30700 + os.getpid() % 1000
+    procs = [mpc.Process(target=_fri_two_rank_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(results) == [(0, True), (1, True)]

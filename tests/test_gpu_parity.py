@@ -349,3 +349,94 @@ def test_fri_commit_2_24_full_size(ctx):
     assert ps.objects == ref_stream.objects
     assert np.array_equal(layers.download(17), ref_layers[17])
     assert np.array_equal(layers.download(5), ref_layers[5])
+
+
+# ---- a Merkle tree / a FRI layer cut across devices ------------------------------
+@pytest.mark.parametrize("chunk_len,n_chunks", [(1, 8), (2, 1), (64, 16), (1 << 10, 4), (1 << 14, 32), (1 << 18, 2)])
+def test_subtree_roots_and_root_of_digests(ctx, chunk_len, n_chunks):
+    """Chunk roots equal Merkle::commit of each chunk; finishing the tree from
+    them equals Merkle::commit of the whole vector (merkle.rs:38-51)."""
+    import torch
+    n = chunk_len * n_chunks
+    x = oc.splitmix(n, 700 + n_chunks)
+    d = torch.from_numpy(x.view(np.int64)).cuda()
+    roots = torch.empty((n_chunks, 32), dtype=torch.uint8, device="cuda")
+    ctx.merkle_subtree_roots_dev(d, chunk_len, n_chunks, roots)
+    ctx.synchronize()
+    got = roots.cpu().numpy()
+    picks = sorted({0, n_chunks // 2, n_chunks - 1})
+    for c in picks:
+        assert got[c].tobytes() == oc.merkle_commit_fe(x[c * chunk_len:(c + 1) * chunk_len])
+    assert ctx.merkle_root_of_digests_dev(roots, n_chunks) == oc.merkle_commit_fe(x)
+
+
+def test_root_of_digests_single_and_errors(ctx):
+    import torch
+    from stark_amd import StarkError
+    d = torch.arange(32, dtype=torch.uint8, device="cuda").view(1, 32)
+    assert ctx.merkle_root_of_digests_dev(d, 1) == bytes(range(32))
+    with pytest.raises(StarkError, match="power of two"):
+        ctx.merkle_root_of_digests_dev(d, 3)
+
+
+@pytest.mark.parametrize("log_n,world,period", [(4, 2, 4), (10, 2, 64), (12, 4, 256), (16, 8, 1 << 10), (20, 4, 1 << 17)])
+def test_fri_fold_shard_vs_oracle(ctx, log_n, world, period):
+    """Every rank's share of the folded layer, and its chunk roots, equal the
+    single-vector fold (fri.rs:133-138) re-dealt the same way."""
+    import torch
+    from stark_amd.distributed import fri_shard_of
+    n = 1 << log_n
+    x = oc.splitmix(n, 800 + log_n)
+    alpha = oc.to_int(oc.splitmix(1, 9)[0])
+    omega, offset = so.primitive_nth_root(n), so.GENERATOR
+    ref = oc.fri_fold(x, alpha, offset, omega)
+    c = period // world
+    full = torch.from_numpy(x.view(np.int64))
+    ref_t = torch.from_numpy(ref.view(np.int64))
+    for rank in sorted({0, world // 2, world - 1}):
+        local = fri_shard_of(full, rank, world, period).cuda()
+        out = torch.empty((local.shape[0] // 2, 2), dtype=torch.int64, device="cuda")
+        n_out_chunks = out.shape[0] // c
+        roots = torch.empty((n_out_chunks, 32), dtype=torch.uint8, device="cuda")
+        ctx.fri_fold_shard_dev(local, local.shape[0], alpha, offset, omega, c, period, rank * c, out, roots)
+        ctx.synchronize()
+        want = fri_shard_of(ref_t, rank, world, period).numpy().view(np.uint64)
+        assert np.array_equal(out.cpu().numpy().view(np.uint64), want)
+        r = roots.cpu().numpy()
+        for q in sorted({0, n_out_chunks - 1}):
+            assert r[q].tobytes() == oc.merkle_commit_fe(np.ascontiguousarray(want[q * c:(q + 1) * c]))
+        out2 = torch.empty_like(out)
+        ctx.fri_fold_shard_dev(local, local.shape[0], alpha, offset, omega, c, period, rank * c, out2)   # no roots
+        ctx.synchronize()
+        assert torch.equal(out, out2)
+
+
+def test_fri_fold_shard_errors(ctx):
+    import torch
+    from stark_amd import StarkError
+    d = torch.zeros((64, 2), dtype=torch.int64, device="cuda")
+    o = torch.zeros((32, 2), dtype=torch.int64, device="cuda")
+    w = so.primitive_nth_root(128)
+    with pytest.raises(StarkError, match="powers of two"):
+        ctx.fri_fold_shard_dev(d, 64, 1, 1, w, 3, 8, 0, o)
+    with pytest.raises(StarkError, match="inside one period"):
+        ctx.fri_fold_shard_dev(d, 64, 1, 1, w, 4, 8, 6, o)
+    with pytest.raises(StarkError, match="inside one period"):
+        ctx.fri_fold_shard_dev(d, 64, 1, 1, w, 16, 8, 0, o)
+    with pytest.raises(StarkError, match="even number of chunks"):
+        ctx.fri_fold_shard_dev(d, 48, 1, 1, w, 16, 32, 0, o)
+    with pytest.raises(StarkError, match="not reduced"):
+        ctx.fri_fold_shard_dev(d, 64, so.P, 1, w, 4, 8, 0, o)
+
+
+def test_library_before_torch_shares_one_hip_runtime():
+    """Creating a context before torch touches the GPU must leave torch able to
+    initialise it (one HIP runtime per process, whichever is loaded first)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("from stark_amd import Context; c = Context(0); import torch; "
+            "t = torch.arange(4, device='cuda'); assert int(t.sum()) == 6; c.close(); print('ok')")
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
