@@ -17,8 +17,11 @@
  *     functions ending in _dev take DEVICE pointers and enqueue on the
  *     context's stream without a host sync (except where a result is returned
  *     to the host, e.g. a root);
- *   - one context per process per GPU; a context is used by one thread at a
- *     time.
+ *   - one context per process per GPU.  Threads may share it: every call
+ *     takes the context's lock (so calls on one context run one at a time,
+ *     a transcript callback may call back in from its own thread) and makes
+ *     the context's device current on the calling thread.  Destroy a context
+ *     only when no call on it, its trees or its layers is in flight.
  */
 #ifndef STARK_HIP_H
 #define STARK_HIP_H

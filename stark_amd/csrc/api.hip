@@ -79,6 +79,7 @@ struct stark_ctx {
     size_t scratch_elems = 0;
     std::multimap<size_t, void*> pool;                 // cached device blocks by size
     void* pinned = nullptr;                            // small pinned staging buffer (4 KiB)
+    std::recursive_mutex mu;
 };
 
 struct stark_tree {
@@ -86,6 +87,15 @@ struct stark_tree {
     digest* d;        // 2n-1 digests
     size_t n;
     bool owns;
+};
+
+// Held for the duration of every entry point: a context is shared by the threads of a
+// process (cargo runs the reference's tests on several), so calls on it are serialised, and the
+// calling thread is pointed at the context's device (the current device is per thread in HIP).
+// Recursive because entry points call one another and a transcript callback may call back in.
+struct CtxGuard {
+    std::unique_lock<std::recursive_mutex> lock;
+    explicit CtxGuard(stark_ctx* c);
 };
 
 struct stark_fri_layers {
@@ -98,6 +108,14 @@ struct stark_fri_layers {
     std::vector<digest*> tree;
     std::vector<std::array<uint8_t, 32>> roots;
 };
+
+CtxGuard::CtxGuard(stark_ctx* c)
+{
+    if (!c) return;
+    lock = std::unique_lock<std::recursive_mutex>(c->mu);
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != c->device) (void)hipSetDevice(c->device);
+}
 
 namespace {
 
@@ -440,18 +458,21 @@ static int32_t roots_batch(stark_ctx* ctx, const uint64_t* elems_dev, size_t n, 
 extern "C" int32_t stark_merkle_roots_fe_batch_dev(stark_ctx* ctx, const uint64_t* elems_dev, size_t n, size_t n_cols,
                                                    size_t col_stride, uint8_t* roots_out)
 {
+    CtxGuard guard_(ctx);
     return roots_batch(ctx, elems_dev, n, n_cols, col_stride, roots_out, false);
 }
 
 extern "C" int32_t stark_merkle_subtree_roots_dev(stark_ctx* ctx, const uint64_t* elems_dev, size_t chunk_len,
                                                   size_t n_chunks, uint8_t* roots_dev_out)
 {
+    CtxGuard guard_(ctx);
     return roots_batch(ctx, elems_dev, chunk_len, n_chunks, chunk_len, roots_dev_out, true);
 }
 
 extern "C" int32_t stark_merkle_root_of_digests_dev(stark_ctx* ctx, const uint8_t* digests_dev, size_t m,
                                                     uint8_t root[32])
 {
+    CtxGuard guard_(ctx);
     if (!ctx || !digests_dev || !root) return fail(STARK_EARG, "null argument");
     if (log2_exact(m) < 0) return fail(STARK_ENOTPOW2, "length must be power of two");
     // the reduction writes every level behind the one it reads: work on a copy with room for them
@@ -531,6 +552,7 @@ extern "C" void stark_ctx_destroy(stark_ctx* ctx)
 
 extern "C" int32_t stark_ctx_set_stream(stark_ctx* ctx, void* hip_stream)
 {
+    CtxGuard guard_(ctx);
     if (!ctx) return fail(STARK_EARG, "null context");
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->stream = (hipStream_t)hip_stream;
@@ -539,6 +561,7 @@ extern "C" int32_t stark_ctx_set_stream(stark_ctx* ctx, void* hip_stream)
 
 extern "C" int32_t stark_ctx_reset_stream(stark_ctx* ctx)
 {
+    CtxGuard guard_(ctx);
     if (!ctx) return fail(STARK_EARG, "null context");
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->stream = ctx->own_stream;
@@ -547,6 +570,7 @@ extern "C" int32_t stark_ctx_reset_stream(stark_ctx* ctx)
 
 extern "C" int32_t stark_ctx_synchronize(stark_ctx* ctx)
 {
+    CtxGuard guard_(ctx);
     if (!ctx) return fail(STARK_EARG, "null context");
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return STARK_OK;
@@ -554,6 +578,7 @@ extern "C" int32_t stark_ctx_synchronize(stark_ctx* ctx)
 
 extern "C" int32_t stark_dev_alloc(stark_ctx* ctx, size_t bytes, void** dptr)
 {
+    CtxGuard guard_(ctx);
     if (!ctx || !dptr) return fail(STARK_EARG, "null argument");
     HIP_TRY(hipMalloc(dptr, bytes ? bytes : 16));
     return STARK_OK;
@@ -561,6 +586,7 @@ extern "C" int32_t stark_dev_alloc(stark_ctx* ctx, size_t bytes, void** dptr)
 
 extern "C" int32_t stark_dev_free(stark_ctx* ctx, void* dptr)
 {
+    CtxGuard guard_(ctx);
     if (!ctx) return fail(STARK_EARG, "null context");
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     HIP_TRY(hipFree(dptr));
@@ -569,6 +595,7 @@ extern "C" int32_t stark_dev_free(stark_ctx* ctx, void* dptr)
 
 extern "C" int32_t stark_copy_h2d(stark_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes)
 {
+    CtxGuard guard_(ctx);
     if (!ctx) return fail(STARK_EARG, "null context");
     HIP_TRY(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -577,6 +604,7 @@ extern "C" int32_t stark_copy_h2d(stark_ctx* ctx, void* dst_dev, const void* src
 
 extern "C" int32_t stark_copy_d2h(stark_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes)
 {
+    CtxGuard guard_(ctx);
     if (!ctx) return fail(STARK_EARG, "null context");
     HIP_TRY(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -598,6 +626,7 @@ static int32_t check_ntt_size(size_t n, int* log_n)
 extern "C" int32_t stark_ntt_batch_dev(stark_ctx* ctx, uint64_t* data_dev, size_t n, size_t n_cols,
                                        size_t col_stride, int32_t inverse)
 {
+    CtxGuard guard_(ctx);
     if (!ctx || (!data_dev && n_cols)) return fail(STARK_EARG, "null argument");
     int log_n;
     ST_TRY(check_ntt_size(n, &log_n));
@@ -608,12 +637,14 @@ extern "C" int32_t stark_ntt_batch_dev(stark_ctx* ctx, uint64_t* data_dev, size_
 
 extern "C" int32_t stark_ntt_dev(stark_ctx* ctx, uint64_t* data_dev, size_t n, int32_t inverse)
 {
+    CtxGuard guard_(ctx);
     return stark_ntt_batch_dev(ctx, data_dev, n, 1, n, inverse);
 }
 
 extern "C" int32_t stark_ntt_batch(stark_ctx* ctx, uint64_t* data, size_t n, size_t n_cols, size_t col_stride,
                                    int32_t inverse)
 {
+    CtxGuard guard_(ctx);
     if (!ctx || (!data && n_cols)) return fail(STARK_EARG, "null argument");
     int log_n;
     ST_TRY(check_ntt_size(n, &log_n));
@@ -631,6 +662,7 @@ extern "C" int32_t stark_ntt_batch(stark_ctx* ctx, uint64_t* data, size_t n, siz
 
 extern "C" int32_t stark_ntt(stark_ctx* ctx, uint64_t* data, size_t n, int32_t inverse)
 {
+    CtxGuard guard_(ctx);
     return stark_ntt_batch(ctx, data, n, 1, n, inverse);
 }
 
@@ -638,6 +670,7 @@ extern "C" int32_t stark_coset_lde_batch_dev(stark_ctx* ctx, const uint64_t* coe
                                              size_t coeff_stride, size_t n_cols, size_t n_out,
                                              const uint64_t offset[2], uint64_t* out_dev, size_t out_stride)
 {
+    CtxGuard guard_(ctx);
     if (!ctx || !offset || (n_cols && (!coeffs_dev || !out_dev))) return fail(STARK_EARG, "null argument");
     int log_n;
     ST_TRY(check_ntt_size(n_out, &log_n));
@@ -655,6 +688,7 @@ extern "C" int32_t stark_coset_lde_batch(stark_ctx* ctx, const uint64_t* coeffs,
                                          size_t coeff_stride, size_t n_cols, size_t n_out,
                                          const uint64_t offset[2], uint64_t* out, size_t out_stride)
 {
+    CtxGuard guard_(ctx);
     if (!ctx || !offset || (n_cols && (!coeffs || !out))) return fail(STARK_EARG, "null argument");
     int log_n;
     ST_TRY(check_ntt_size(n_out, &log_n));
@@ -685,6 +719,7 @@ extern "C" int32_t stark_coset_lde_batch(stark_ctx* ctx, const uint64_t* coeffs,
 extern "C" int32_t stark_vec_mul_dev(stark_ctx* ctx, const uint64_t* a_dev, const uint64_t* b_dev,
                                      uint64_t* out_dev, size_t n)
 {
+    CtxGuard guard_(ctx);
     if (!ctx || (n && (!a_dev || !b_dev || !out_dev))) return fail(STARK_EARG, "null argument");
     HIP_TRY(launch_vec_mul((const fe*)a_dev, (const fe*)b_dev, (fe*)out_dev, n, ctx->F.r2, ctx->stream));
     return STARK_OK;
@@ -692,6 +727,7 @@ extern "C" int32_t stark_vec_mul_dev(stark_ctx* ctx, const uint64_t* a_dev, cons
 
 extern "C" int32_t stark_vec_mul(stark_ctx* ctx, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n)
 {
+    CtxGuard guard_(ctx);
     if (!ctx || (n && (!a || !b || !out))) return fail(STARK_EARG, "null argument");
     if (n == 0) return STARK_OK;
     DevBuf da(ctx), db(ctx);
@@ -708,6 +744,7 @@ extern "C" int32_t stark_vec_mul(stark_ctx* ctx, const uint64_t* a, const uint64
 extern "C" int32_t stark_fourstep_twiddle_dev(stark_ctx* ctx, uint64_t* data_dev, size_t n_total, size_t row_start,
                                               size_t n_rows, size_t n_cols, int32_t inverse)
 {
+    CtxGuard guard_(ctx);
     if (!ctx || (!data_dev && n_rows * n_cols)) return fail(STARK_EARG, "null argument");
     int log_n;
     ST_TRY(check_ntt_size(n_total, &log_n));
@@ -730,6 +767,7 @@ extern "C" int32_t stark_fourstep_twiddle_dev(stark_ctx* ctx, uint64_t* data_dev
 extern "C" int32_t stark_merkle_commit_fe_dev(stark_ctx* ctx, const uint64_t* elems_dev, size_t n,
                                               uint8_t root[32], stark_tree** tree_out)
 {
+    CtxGuard guard_(ctx);
     if (!ctx || !elems_dev || !root) return fail(STARK_EARG, "null argument");
     return tree_build(ctx, (const fe*)elems_dev, n, root, tree_out);
 }
@@ -737,6 +775,7 @@ extern "C" int32_t stark_merkle_commit_fe_dev(stark_ctx* ctx, const uint64_t* el
 extern "C" int32_t stark_merkle_commit_fe(stark_ctx* ctx, const uint64_t* elems, size_t n, uint8_t root[32],
                                           stark_tree** tree_out)
 {
+    CtxGuard guard_(ctx);
     if (!ctx || !elems || !root) return fail(STARK_EARG, "null argument");
     if (log2_exact(n) < 0) return fail(STARK_ENOTPOW2, "length must be power of two");
     DevBuf buf(ctx);
@@ -748,6 +787,7 @@ extern "C" int32_t stark_merkle_commit_fe(stark_ctx* ctx, const uint64_t* elems,
 extern "C" int32_t stark_merkle_commit_bytes(stark_ctx* ctx, const uint8_t* flat, const uint64_t* offsets,
                                              size_t n, uint8_t root[32], stark_tree** tree_out)
 {
+    CtxGuard guard_(ctx);
     if (!ctx || !offsets || !root) return fail(STARK_EARG, "null argument");
     if (log2_exact(n) < 0) return fail(STARK_ENOTPOW2, "length must be power of two");
     const size_t total = (size_t)offsets[n];
@@ -777,6 +817,7 @@ extern "C" int32_t stark_merkle_commit_bytes(stark_ctx* ctx, const uint8_t* flat
 
 extern "C" int32_t stark_merkle_open(stark_tree* tree, size_t index, uint8_t* path_out, size_t* depth_out)
 {
+    CtxGuard guard_(tree ? tree->ctx : nullptr);
     if (!tree || !path_out) return fail(STARK_EARG, "null argument");
     return tree_open(tree->ctx, tree->d, tree->n, index, path_out, depth_out);
 }
@@ -785,6 +826,7 @@ extern "C" size_t stark_tree_num_leaves(const stark_tree* tree) { return tree ? 
 
 extern "C" int32_t stark_tree_download(stark_tree* tree, uint8_t* out)
 {
+    CtxGuard guard_(tree ? tree->ctx : nullptr);
     if (!tree || !out) return fail(STARK_EARG, "null argument");
     HIP_TRY(hipMemcpyAsync(out, tree->d, (2 * tree->n - 1) * sizeof(digest), hipMemcpyDeviceToHost,
                            tree->ctx->stream));
@@ -794,6 +836,7 @@ extern "C" int32_t stark_tree_download(stark_tree* tree, uint8_t* out)
 
 extern "C" void stark_tree_free(stark_tree* tree)
 {
+    CtxGuard guard_(tree ? tree->ctx : nullptr);
     if (!tree) return;
     if (tree->owns) {
         (void)hipStreamSynchronize(tree->ctx->stream);
@@ -831,6 +874,7 @@ extern "C" int32_t stark_fri_fold_dev(stark_ctx* ctx, const uint64_t* codeword_d
                                       const uint64_t alpha[2], const uint64_t offset[2], const uint64_t omega[2],
                                       uint64_t* out_dev)
 {
+    CtxGuard guard_(ctx);
     if (!ctx || !codeword_dev || !alpha || !offset || !omega || !out_dev) return fail(STARK_EARG, "null argument");
     if (N < 2 || (N & 1)) return fail(STARK_ELENGTH, "codeword length must be even");
     fe al{alpha[0], alpha[1]}, of{offset[0], offset[1]}, om{omega[0], omega[1]};
@@ -855,6 +899,7 @@ extern "C" int32_t stark_fri_fold_shard_dev(stark_ctx* ctx, const uint64_t* loca
                                             size_t chunk_len, size_t period, size_t base, uint64_t* out_dev,
                                             uint8_t* chunk_roots_dev_out)
 {
+    CtxGuard guard_(ctx);
     if (!ctx || !local_dev || !alpha || !offset || !omega || !out_dev) return fail(STARK_EARG, "null argument");
     const int log_chunk = log2_exact(chunk_len), log_period = log2_exact(period);
     if (log_chunk < 0 || log_period < 0) return fail(STARK_ENOTPOW2, "chunk length and period must be powers of two");
@@ -899,6 +944,7 @@ extern "C" int32_t stark_fri_fold_shard_dev(stark_ctx* ctx, const uint64_t* loca
 extern "C" int32_t stark_fri_fold(stark_ctx* ctx, const uint64_t* codeword, size_t N, const uint64_t alpha[2],
                                   const uint64_t offset[2], const uint64_t omega[2], uint64_t* out)
 {
+    CtxGuard guard_(ctx);
     if (!ctx || !codeword || !out) return fail(STARK_EARG, "null argument");
     if (N < 2 || (N & 1)) return fail(STARK_ELENGTH, "codeword length must be even");
     DevBuf in(ctx), ob(ctx);
@@ -1021,6 +1067,7 @@ extern "C" int32_t stark_fri_commit_dev(stark_ctx* ctx, const uint64_t* codeword
                                         size_t num_colinearity_tests, stark_transcript_cb cb, void* user,
                                         stark_fri_layers** layers_out)
 {
+    CtxGuard guard_(ctx);
     return fri_commit_impl(ctx, (const fe*)codeword_dev, false, N, offset, omega, expansion_factor,
                            num_colinearity_tests, cb, user, layers_out);
 }
@@ -1029,6 +1076,7 @@ extern "C" int32_t stark_fri_commit(stark_ctx* ctx, const uint64_t* codeword, si
                                     const uint64_t omega[2], size_t expansion_factor, size_t num_colinearity_tests,
                                     stark_transcript_cb cb, void* user, stark_fri_layers** layers_out)
 {
+    CtxGuard guard_(ctx);
     return fri_commit_impl(ctx, (const fe*)codeword, true, N, offset, omega, expansion_factor,
                            num_colinearity_tests, cb, user, layers_out);
 }
@@ -1049,6 +1097,7 @@ extern "C" int32_t stark_fri_layer_root(const stark_fri_layers* l, size_t layer,
 
 extern "C" int32_t stark_fri_layer_download(stark_fri_layers* l, size_t layer, uint64_t* out)
 {
+    CtxGuard guard_(l ? l->ctx : nullptr);
     if (!l || !out || layer >= l->len.size()) return fail(STARK_EARG, "bad layer");
     HIP_TRY(hipMemcpyAsync(out, l->cw[layer], l->len[layer] * sizeof(fe), hipMemcpyDeviceToHost, l->ctx->stream));
     HIP_TRY(hipStreamSynchronize(l->ctx->stream));
@@ -1058,6 +1107,7 @@ extern "C" int32_t stark_fri_layer_download(stark_fri_layers* l, size_t layer, u
 extern "C" int32_t stark_fri_layer_read(stark_fri_layers* l, size_t layer, const uint64_t* indices, size_t count,
                                         uint64_t* out)
 {
+    CtxGuard guard_(l ? l->ctx : nullptr);
     if (!l || !indices || !out || layer >= l->len.size()) return fail(STARK_EARG, "bad layer");
     if (count == 0) return STARK_OK;
     for (size_t i = 0; i < count; i++)
@@ -1076,12 +1126,14 @@ extern "C" int32_t stark_fri_layer_read(stark_fri_layers* l, size_t layer, const
 extern "C" int32_t stark_fri_layer_open(stark_fri_layers* l, size_t layer, size_t index, uint8_t* path_out,
                                         size_t* depth_out)
 {
+    CtxGuard guard_(l ? l->ctx : nullptr);
     if (!l || !path_out || layer >= l->len.size()) return fail(STARK_EARG, "bad layer");
     return tree_open(l->ctx, l->tree[layer], l->len[layer], index, path_out, depth_out);
 }
 
 extern "C" void stark_fri_layers_free(stark_fri_layers* l)
 {
+    CtxGuard guard_(l ? l->ctx : nullptr);
     if (!l) return;
     (void)hipStreamSynchronize(l->ctx->stream);
     pool_free(l->ctx, l->cw_arena, l->cw_bytes);

@@ -440,3 +440,32 @@ def test_library_before_torch_shares_one_hip_runtime():
             "t = torch.arange(4, device='cuda'); assert int(t.sum()) == 6; c.close(); print('ok')")
     r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=240)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
+
+
+def test_one_context_from_several_threads(ctx):
+    """Calls on one context from several threads are serialised inside the
+    library (the reference's tests run on cargo's thread pool): every thread
+    gets the results a lone caller gets."""
+    import threading
+    jobs = [(12, 31), (14, 32), (10, 33), (16, 34), (13, 35), (11, 36)]
+    want = {}
+    for log_n, seed in jobs:
+        x = oc.splitmix(1 << log_n, seed)
+        want[seed] = (x, oc.ntt(x), oc.merkle_commit_fe(x))
+    errors = []
+
+    def work(log_n, seed):
+        try:
+            x, f, root = want[seed]
+            for _ in range(5):
+                assert np.array_equal(ctx.ntt(x), f)
+                assert ctx.merkle_commit_fe(x) == root
+        except BaseException as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=work, args=j) for j in jobs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not errors, errors
