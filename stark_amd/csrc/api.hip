@@ -479,11 +479,12 @@ extern "C" int32_t stark_merkle_root_of_digests_dev(stark_ctx* ctx, const uint8_
     DevBuf levels(ctx);
     ST_TRY(levels.alloc((2 * m - 1) * sizeof(digest)));
     HIP_TRY(hipMemcpyAsync(levels.p, digests_dev, m * sizeof(digest), hipMemcpyDeviceToDevice, ctx->stream));
-    digest* top = nullptr;
-    HIP_TRY(launch_merkle_reduce((digest*)levels.p, m, ctx->stream, nullptr, 1, &top));
-    HIP_TRY(hipMemcpyAsync(ctx->pinned, top, sizeof(digest), hipMemcpyDeviceToHost, ctx->stream));
+    // the last launch writes the root straight into host-mapped pinned memory; one digest has no launch
+    digest* root_mail = (digest*)((uint8_t*)ctx->pinned + 2048);
+    if (m == 1) HIP_TRY(hipMemcpyAsync(root_mail, levels.p, sizeof(digest), hipMemcpyDeviceToHost, ctx->stream));
+    else HIP_TRY(launch_merkle_reduce((digest*)levels.p, m, ctx->stream, root_mail));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    memcpy(root, ctx->pinned, 32);
+    memcpy(root, root_mail, 32);
     return STARK_OK;
 }
 

@@ -56,9 +56,13 @@ __device__ __forceinline__ digest node2(const digest& l, const digest& r)
     return hash2<8>(m, 64);
 }
 
-template <int KIND> __global__ __launch_bounds__(256) void chain_kernel(digest* out, uint64_t seed)
+// clk[0..1]: shader-clock and 100 MHz wall-clock ticks spent by one wave in the middle of the grid
+template <int KIND> __global__ __launch_bounds__(256) void chain_kernel(digest* out, uint64_t seed, uint64_t* clk = nullptr)
 {
     uint64_t gid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool probe = clk && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0;
+    uint64_t c0 = 0, w0 = 0;
+    if (probe) { c0 = clock64(); w0 = wall_clock64(); }
     digest d;
     d.w[0] = seed + gid; d.w[1] = seed ^ (gid << 20); d.w[2] = gid * 0x9E3779B97F4A7C15ull; d.w[3] = ~gid;
 #pragma clang loop unroll(disable)
@@ -68,6 +72,7 @@ template <int KIND> __global__ __launch_bounds__(256) void chain_kernel(digest* 
         else d = node2(d, d);
     }
     if (d.w[0] == 0x1234567) out[0] = d;
+    if (probe) { clk[0] = clock64() - c0; clk[1] = wall_clock64() - w0; }
 }
 
 // node level with memory traffic: K parents per thread, grid-stride so a wave's loads stay coalesced
@@ -110,7 +115,12 @@ template <int KIND> int run(const char* name, digest* buf)
     CHECK(hipEventSynchronize(e1));
     float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
     double hashes = 3.0 * blocks * 256 * CHAIN;
-    printf("%-24s %8.3f ms  %7.2f Ghash/s\n", name, ms, hashes / (ms * 1e-3) / 1e9);
+    uint64_t* clk; CHECK(hipMalloc(&clk, 16));
+    hipLaunchKernelGGL(chain_kernel<KIND>, dim3(blocks), dim3(256), 0, 0, buf, 9ull, clk);
+    uint64_t h[2]; CHECK(hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost));
+    printf("%-24s %8.3f ms  %7.2f Ghash/s   shader clock under this load %.2f GHz\n", name, ms,
+           hashes / (ms * 1e-3) / 1e9, (double)h[0] / ((double)h[1] * 10.0));
+    CHECK(hipFree(clk));
     return 0;
 }
 
