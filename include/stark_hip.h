@@ -129,16 +129,24 @@ int32_t stark_merkle_roots_fe_batch_dev(stark_ctx* ctx, const uint64_t* elems_de
  * (roots_dev_out: n_chunks x 32 bytes of device memory, not synchronised), and
  * stark_merkle_root_of_digests_dev finishes the tree from all m subtree roots
  * in leaf order (device memory, m a power of two; root is host memory).  The
- * root equals Merkle::commit over all the leaves. */
+ * root equals Merkle::commit over all the leaves.
+ * Both can keep what they built for Merkle::open (merkle.rs:54-93): *forest_out
+ * (n_chunks then a power of two) answers stark_merkle_open(forest, local leaf
+ * index) with the log2(chunk_len) siblings inside that leaf's subtree, and
+ * *tree_out answers stark_merkle_open(tree, chunk index) with the siblings from
+ * the subtree root up; one after the other they are the path of the whole tree.
+ * Pass NULL to keep nothing. */
 int32_t stark_merkle_subtree_roots_dev(stark_ctx* ctx, const uint64_t* elems_dev, size_t chunk_len,
-                                       size_t n_chunks, uint8_t* roots_dev_out);
-int32_t stark_merkle_root_of_digests_dev(stark_ctx* ctx, const uint8_t* digests_dev, size_t m, uint8_t root[32]);
+                                       size_t n_chunks, uint8_t* roots_dev_out, stark_tree** forest_out);
+int32_t stark_merkle_root_of_digests_dev(stark_ctx* ctx, const uint8_t* digests_dev, size_t m, uint8_t root[32],
+                                         stark_tree** tree_out);
 /* Merkle::commit(&Vec<Vec<u8>>) for arbitrary byte leaves: leaf i is
  * flat[offsets[i] .. offsets[i+1]) (host pointers). */
 int32_t stark_merkle_commit_bytes(stark_ctx* ctx, const uint8_t* flat, const uint64_t* offsets, size_t n,
                                   uint8_t root[32], stark_tree** tree_out);
 /* Merkle::open (merkle.rs:54-93): path[0] = sibling leaf digest ... last =
- * sibling of the root's child; writes log2(n) digests of 32 bytes. */
+ * sibling of the root's child; writes log2(n) digests of 32 bytes (for a
+ * forest handle: log2(chunk_len), the siblings below the subtree root). */
 int32_t stark_merkle_open(stark_tree* tree, size_t index, uint8_t* path_out, size_t* depth_out);
 size_t stark_tree_num_leaves(const stark_tree* tree);
 /* All 2n-1 digests, leaf level first, each level followed by its parent level. */
@@ -162,11 +170,12 @@ int32_t stark_fri_fold_dev(stark_ctx* ctx, const uint64_t* codeword_dev, size_t 
  * elements); omega and offset are those of the layer being folded.  If
  * chunk_roots_dev_out is not NULL it receives the subtree root of every output
  * chunk (local_len/2/chunk_len x 32 bytes, device memory), as
- * stark_merkle_subtree_roots_dev would compute them.  Not synchronised. */
+ * stark_merkle_subtree_roots_dev would compute them, and *forest_out, if not
+ * NULL, keeps those subtrees for openings in the same way.  Not synchronised. */
 int32_t stark_fri_fold_shard_dev(stark_ctx* ctx, const uint64_t* local_dev, size_t local_len,
                                  const uint64_t alpha[2], const uint64_t offset[2], const uint64_t omega[2],
                                  size_t chunk_len, size_t period, size_t base, uint64_t* out_dev,
-                                 uint8_t* chunk_roots_dev_out);
+                                 uint8_t* chunk_roots_dev_out, stark_tree** forest_out);
 
 /* Fri::num_rounds (fri.rs:39-51). */
 size_t stark_fri_num_rounds(size_t domain_length, size_t expansion_factor, size_t num_colinearity_tests);

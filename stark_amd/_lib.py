@@ -43,8 +43,8 @@ SIGNATURES = {
     "stark_merkle_commit_fe": (i32, [C.c_void_p, C.c_void_p, sz, u8p, voidpp]),
     "stark_merkle_commit_fe_dev": (i32, [C.c_void_p, C.c_void_p, sz, u8p, voidpp]),
     "stark_merkle_roots_fe_batch_dev": (i32, [C.c_void_p, C.c_void_p, sz, sz, sz, C.c_void_p]),
-    "stark_merkle_subtree_roots_dev": (i32, [C.c_void_p, C.c_void_p, sz, sz, C.c_void_p]),
-    "stark_merkle_root_of_digests_dev": (i32, [C.c_void_p, C.c_void_p, sz, u8p]),
+    "stark_merkle_subtree_roots_dev": (i32, [C.c_void_p, C.c_void_p, sz, sz, C.c_void_p, voidpp]),
+    "stark_merkle_root_of_digests_dev": (i32, [C.c_void_p, C.c_void_p, sz, u8p, voidpp]),
     "stark_merkle_commit_bytes": (i32, [C.c_void_p, C.c_void_p, C.c_void_p, sz, u8p, voidpp]),
     "stark_merkle_open": (i32, [C.c_void_p, sz, u8p, szp]),
     "stark_tree_num_leaves": (sz, [C.c_void_p]),
@@ -53,7 +53,7 @@ SIGNATURES = {
     "stark_fri_fold": (i32, [C.c_void_p, C.c_void_p, sz, u64p, u64p, u64p, C.c_void_p]),
     "stark_fri_fold_dev": (i32, [C.c_void_p, C.c_void_p, sz, u64p, u64p, u64p, C.c_void_p]),
     "stark_fri_fold_shard_dev": (i32, [C.c_void_p, C.c_void_p, sz, u64p, u64p, u64p, sz, sz, sz, C.c_void_p,
-                                       C.c_void_p]),
+                                       C.c_void_p, voidpp]),
     "stark_fri_num_rounds": (sz, [sz, sz, sz]),
     "stark_fri_commit": (i32, [C.c_void_p, C.c_void_p, sz, u64p, u64p, sz, sz, TRANSCRIPT_CB, C.c_void_p, voidpp]),
     "stark_fri_commit_dev": (i32, [C.c_void_p, C.c_void_p, sz, u64p, u64p, sz, sz, TRANSCRIPT_CB, C.c_void_p, voidpp]),

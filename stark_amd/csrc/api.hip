@@ -87,6 +87,9 @@ struct stark_tree {
     digest* d;        // 2n-1 digests
     size_t n;
     bool owns;
+    // levels above the leaves that hold digests: log2(n) for a whole tree; log2(chunk) for a forest
+    // of equal subtrees side by side (same layout, the levels above the subtree roots never computed)
+    uint32_t levels;
 };
 
 // Held for the duration of every entry point: a context is shared by the threads of a
@@ -419,7 +422,7 @@ static int32_t tree_build(stark_ctx* ctx, const fe* elems_dev, size_t n, uint8_t
     }
     memcpy(root, ctx->pinned, 32);
     if (tree_out) {
-        *tree_out = new stark_tree{ctx, tree, n, true};
+        *tree_out = new stark_tree{ctx, tree, n, true, (uint32_t)log2_exact(n)};
     } else {
         pool_free(ctx, d, bytes);
     }
@@ -463,43 +466,72 @@ extern "C" int32_t stark_merkle_roots_fe_batch_dev(stark_ctx* ctx, const uint64_
 }
 
 extern "C" int32_t stark_merkle_subtree_roots_dev(stark_ctx* ctx, const uint64_t* elems_dev, size_t chunk_len,
-                                                  size_t n_chunks, uint8_t* roots_dev_out)
+                                                  size_t n_chunks, uint8_t* roots_dev_out, stark_tree** forest_out)
 {
     CtxGuard guard_(ctx);
-    return roots_batch(ctx, elems_dev, chunk_len, n_chunks, chunk_len, roots_dev_out, true);
+    if (!forest_out) return roots_batch(ctx, elems_dev, chunk_len, n_chunks, chunk_len, roots_dev_out, true);
+    if (!ctx || !elems_dev || !roots_dev_out) return fail(STARK_EARG, "null argument");
+    const int log_c = log2_exact(chunk_len);
+    if (log_c < 0) return fail(STARK_ENOTPOW2, "length must be power of two");
+    const size_t total = chunk_len * n_chunks;
+    if (log2_exact(total) < 0) return fail(STARK_ENOTPOW2, "a retained forest needs a power-of-two number of chunks");
+    // all subtrees in one buffer laid out like one tree over all the leaves, cut off at the subtree roots
+    const size_t bytes = (2 * total - 1) * sizeof(digest);
+    void* d = nullptr;
+    ST_TRY(pool_alloc(ctx, bytes, &d));
+    digest* roots = nullptr;
+    hipError_t e = launch_leaf_hash_batch((const fe*)elems_dev, chunk_len, (digest*)d, (uint32_t)log_c, n_chunks, ctx->stream);
+    if (e == hipSuccess) e = launch_merkle_reduce((digest*)d, total, ctx->stream, nullptr, n_chunks, &roots);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(roots_dev_out, roots, n_chunks * sizeof(digest), hipMemcpyDeviceToDevice, ctx->stream);
+    if (e != hipSuccess) {
+        pool_free(ctx, d, bytes);
+        return fail(STARK_EHIP, std::string("subtree roots: ") + hipGetErrorString(e));
+    }
+    *forest_out = new stark_tree{ctx, (digest*)d, total, true, (uint32_t)log_c};
+    return STARK_OK;
 }
 
 extern "C" int32_t stark_merkle_root_of_digests_dev(stark_ctx* ctx, const uint8_t* digests_dev, size_t m,
-                                                    uint8_t root[32])
+                                                    uint8_t root[32], stark_tree** tree_out)
 {
     CtxGuard guard_(ctx);
     if (!ctx || !digests_dev || !root) return fail(STARK_EARG, "null argument");
     if (log2_exact(m) < 0) return fail(STARK_ENOTPOW2, "length must be power of two");
     // the reduction writes every level behind the one it reads: work on a copy with room for them
-    DevBuf levels(ctx);
-    ST_TRY(levels.alloc((2 * m - 1) * sizeof(digest)));
-    HIP_TRY(hipMemcpyAsync(levels.p, digests_dev, m * sizeof(digest), hipMemcpyDeviceToDevice, ctx->stream));
+    const size_t bytes = (2 * m - 1) * sizeof(digest);
+    void* d = nullptr;
+    ST_TRY(pool_alloc(ctx, bytes, &d));
     // the last launch writes the root straight into host-mapped pinned memory; one digest has no launch
     digest* root_mail = (digest*)((uint8_t*)ctx->pinned + 2048);
-    if (m == 1) HIP_TRY(hipMemcpyAsync(root_mail, levels.p, sizeof(digest), hipMemcpyDeviceToHost, ctx->stream));
-    else HIP_TRY(launch_merkle_reduce((digest*)levels.p, m, ctx->stream, root_mail));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    hipError_t e = hipMemcpyAsync(d, digests_dev, m * sizeof(digest), hipMemcpyDeviceToDevice, ctx->stream);
+    if (e == hipSuccess)
+        e = m == 1 ? hipMemcpyAsync(root_mail, d, sizeof(digest), hipMemcpyDeviceToHost, ctx->stream)
+                   : launch_merkle_reduce((digest*)d, m, ctx->stream, root_mail);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        pool_free(ctx, d, bytes);
+        return fail(STARK_EHIP, std::string("root of digests: ") + hipGetErrorString(e));
+    }
     memcpy(root, root_mail, 32);
+    if (tree_out) *tree_out = new stark_tree{ctx, (digest*)d, m, true, (uint32_t)log2_exact(m)};
+    else pool_free(ctx, d, bytes);
     return STARK_OK;
 }
 
 static int32_t tree_open(stark_ctx* ctx, const digest* tree, size_t n, size_t index, uint8_t* path_out,
-                         size_t* depth_out)
+                         size_t* depth_out, int max_levels = 64)
 {
     int depth = log2_exact(n);
     if (depth < 0) return fail(STARK_ENOTPOW2, "length must be power of two");
+    if (depth > max_levels) depth = max_levels;
     if (index >= n) return fail(STARK_EINDEX, "cannot open invalid index");
     if (depth_out) *depth_out = (size_t)depth;
     if (depth == 0) return STARK_OK;
     digest* stage = (digest*)((uint8_t*)ctx->pinned + 64);     // 4 KiB pinned buffer: depth <= 30 digests fit
     DevBuf tmp(ctx);
     ST_TRY(tmp.alloc((size_t)depth * sizeof(digest)));
-    HIP_TRY(launch_merkle_open(tree, n, index, (digest*)tmp.p, ctx->stream));
+    HIP_TRY(launch_merkle_open(tree, n, index, (digest*)tmp.p, ctx->stream, (uint32_t)depth));
     HIP_TRY(hipMemcpyAsync(stage, tmp.p, (size_t)depth * sizeof(digest), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     memcpy(path_out, stage, (size_t)depth * sizeof(digest));
@@ -811,7 +843,7 @@ extern "C" int32_t stark_merkle_commit_bytes(stark_ctx* ctx, const uint8_t* flat
         return fail(STARK_EHIP, std::string("merkle commit: ") + hipGetErrorString(e));
     }
     memcpy(root, ctx->pinned, 32);
-    if (tree_out) *tree_out = new stark_tree{ctx, tree, n, true};
+    if (tree_out) *tree_out = new stark_tree{ctx, tree, n, true, (uint32_t)log2_exact(n)};
     else pool_free(ctx, d, bytes);
     return STARK_OK;
 }
@@ -820,7 +852,7 @@ extern "C" int32_t stark_merkle_open(stark_tree* tree, size_t index, uint8_t* pa
 {
     CtxGuard guard_(tree ? tree->ctx : nullptr);
     if (!tree || !path_out) return fail(STARK_EARG, "null argument");
-    return tree_open(tree->ctx, tree->d, tree->n, index, path_out, depth_out);
+    return tree_open(tree->ctx, tree->d, tree->n, index, path_out, depth_out, (int)tree->levels);
 }
 
 extern "C" size_t stark_tree_num_leaves(const stark_tree* tree) { return tree ? tree->n : 0; }
@@ -829,6 +861,7 @@ extern "C" int32_t stark_tree_download(stark_tree* tree, uint8_t* out)
 {
     CtxGuard guard_(tree ? tree->ctx : nullptr);
     if (!tree || !out) return fail(STARK_EARG, "null argument");
+    if (tree->levels != (uint32_t)log2_exact(tree->n)) return fail(STARK_EARG, "a forest of subtrees has no upper levels to download");
     HIP_TRY(hipMemcpyAsync(out, tree->d, (2 * tree->n - 1) * sizeof(digest), hipMemcpyDeviceToHost,
                            tree->ctx->stream));
     HIP_TRY(hipStreamSynchronize(tree->ctx->stream));
@@ -898,7 +931,7 @@ extern "C" int32_t stark_fri_fold_dev(stark_ctx* ctx, const uint64_t* codeword_d
 extern "C" int32_t stark_fri_fold_shard_dev(stark_ctx* ctx, const uint64_t* local_dev, size_t local_len,
                                             const uint64_t alpha[2], const uint64_t offset[2], const uint64_t omega[2],
                                             size_t chunk_len, size_t period, size_t base, uint64_t* out_dev,
-                                            uint8_t* chunk_roots_dev_out)
+                                            uint8_t* chunk_roots_dev_out, stark_tree** forest_out)
 {
     CtxGuard guard_(ctx);
     if (!ctx || !local_dev || !alpha || !offset || !omega || !out_dev) return fail(STARK_EARG, "null argument");
@@ -928,17 +961,28 @@ extern "C" int32_t stark_fri_fold_shard_dev(stark_ctx* ctx, const uint64_t* loca
     a.log_period = (uint32_t)log_period;
     a.base = base;
     if (!chunk_roots_dev_out) {
+        if (forest_out) return fail(STARK_EARG, "a forest is only kept together with its roots");
         HIP_TRY(launch_fri_fold(a, ctx->stream));
         return STARK_OK;
     }
+    if (forest_out && log2_exact(half) < 0)
+        return fail(STARK_ENOTPOW2, "a retained forest needs a power-of-two number of chunks");
     // leaf digests of the outputs in the same pass, then one subtree per output chunk
-    DevBuf trees(ctx);
-    ST_TRY(trees.alloc((2 * half - 1) * sizeof(digest)));
-    a.leaf_out = (digest*)trees.p;
-    HIP_TRY(launch_fri_fold(a, ctx->stream));
+    const size_t bytes = (2 * half - 1) * sizeof(digest);
+    void* d = nullptr;
+    ST_TRY(pool_alloc(ctx, bytes, &d));
+    a.leaf_out = (digest*)d;
     digest* roots = nullptr;
-    HIP_TRY(launch_merkle_reduce(a.leaf_out, half, ctx->stream, nullptr, chunks_out, &roots));
-    HIP_TRY(hipMemcpyAsync(chunk_roots_dev_out, roots, chunks_out * sizeof(digest), hipMemcpyDeviceToDevice, ctx->stream));
+    hipError_t e = launch_fri_fold(a, ctx->stream);
+    if (e == hipSuccess) e = launch_merkle_reduce(a.leaf_out, half, ctx->stream, nullptr, chunks_out, &roots);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(chunk_roots_dev_out, roots, chunks_out * sizeof(digest), hipMemcpyDeviceToDevice, ctx->stream);
+    if (e != hipSuccess) {
+        pool_free(ctx, d, bytes);
+        return fail(STARK_EHIP, std::string("fold shard: ") + hipGetErrorString(e));
+    }
+    if (forest_out) *forest_out = new stark_tree{ctx, (digest*)d, half, true, (uint32_t)log_chunk};
+    else pool_free(ctx, d, bytes);
     return STARK_OK;
 }
 

@@ -425,10 +425,12 @@ __global__ void merkle_open_kernel(const digest* __restrict__ tree, size_t n, si
     if (m > 1) path[k] = tree[off + ((index >> k) ^ 1)];
 }
 
-hipError_t launch_merkle_open(const digest* tree, size_t n, size_t index, digest* path_out, hipStream_t s)
+hipError_t launch_merkle_open(const digest* tree, size_t n, size_t index, digest* path_out, hipStream_t s,
+                              uint32_t max_levels)
 {
     uint32_t depth = 0;
     while (((size_t)1 << depth) < n) depth++;
+    if (depth > max_levels) depth = max_levels;
     if (depth == 0) return hipSuccess;
     hipLaunchKernelGGL(merkle_open_kernel, dim3(1), dim3(depth), 0, s, tree, n, index, path_out);
     return hipGetLastError();

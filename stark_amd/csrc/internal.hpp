@@ -106,7 +106,9 @@ hipError_t launch_fri_fold(const FoldArgs& a, hipStream_t s);
 hipError_t launch_fri_fold_commit(const FoldArgs& a, hipStream_t s, digest* root_out);
 
 // Authentication path of `index` (merkle.rs:54-93): depth digests, sibling leaf first.
-hipError_t launch_merkle_open(const digest* tree, size_t n, size_t index, digest* path_out, hipStream_t s);
+// (only the lowest max_levels siblings if that is less than the depth)
+hipError_t launch_merkle_open(const digest* tree, size_t n, size_t index, digest* path_out, hipStream_t s,
+                              uint32_t max_levels = 64);
 
 hipError_t launch_gather_fe(const fe* src, const uint64_t* idx, fe* out, size_t count, hipStream_t s);
 

@@ -223,15 +223,21 @@ class Context:
         raw = bytes(roots)
         return [raw[32 * c:32 * (c + 1)] for c in range(n_cols)]
 
-    def merkle_subtree_roots_dev(self, dptr, chunk_len: int, n_chunks: int, roots_dptr):
-        """Subtree root of each of n_chunks aligned runs of chunk_len leaves, left in device memory."""
-        self._chk(self.lib.stark_merkle_subtree_roots_dev(self.h, _ptr(dptr), chunk_len, n_chunks, _ptr(roots_dptr)))
+    def merkle_subtree_roots_dev(self, dptr, chunk_len: int, n_chunks: int, roots_dptr, keep_forest: bool = False):
+        """Subtree root of each of n_chunks aligned runs of chunk_len leaves, left in device memory.
+        With keep_forest returns a Tree whose open(local leaf index) gives the siblings inside the subtree."""
+        th = C.c_void_p()
+        self._chk(self.lib.stark_merkle_subtree_roots_dev(self.h, _ptr(dptr), chunk_len, n_chunks, _ptr(roots_dptr),
+                                                          C.byref(th) if keep_forest else None))
+        return Tree(self, th) if keep_forest else None
 
-    def merkle_root_of_digests_dev(self, dptr, m: int) -> bytes:
+    def merkle_root_of_digests_dev(self, dptr, m: int, keep_tree: bool = False):
         """Root of the tree whose lowest level is the m digests at dptr (device memory)."""
         root = (C.c_uint8 * 32)()
-        self._chk(self.lib.stark_merkle_root_of_digests_dev(self.h, _ptr(dptr), m, root))
-        return bytes(root)
+        th = C.c_void_p()
+        self._chk(self.lib.stark_merkle_root_of_digests_dev(self.h, _ptr(dptr), m, root,
+                                                            C.byref(th) if keep_tree else None))
+        return (bytes(root), Tree(self, th)) if keep_tree else bytes(root)
 
     def merkle_commit_bytes(self, leaves: Sequence[bytes], keep_tree: bool = False):
         flat = np.frombuffer(b"".join(leaves) or b"\0", dtype=np.uint8).copy()
@@ -257,10 +263,13 @@ class Context:
                                               _ptr(out_ptr)))
 
     def fri_fold_shard_dev(self, local_ptr, local_len: int, alpha: int, offset: int, omega: int, chunk_len: int,
-                           period: int, base: int, out_ptr, chunk_roots_ptr=None):
+                           period: int, base: int, out_ptr, chunk_roots_ptr=None, keep_forest: bool = False):
+        th = C.c_void_p()
         self._chk(self.lib.stark_fri_fold_shard_dev(self.h, _ptr(local_ptr), local_len, _fe(alpha), _fe(offset),
                                                     _fe(omega), chunk_len, period, base, _ptr(out_ptr),
-                                                    None if chunk_roots_ptr is None else _ptr(chunk_roots_ptr)))
+                                                    None if chunk_roots_ptr is None else _ptr(chunk_roots_ptr),
+                                                    C.byref(th) if keep_forest else None))
+        return Tree(self, th) if keep_forest else None
 
     def fri_num_rounds(self, domain_length: int, expansion_factor: int, num_colinearity_tests: int) -> int:
         return self.lib.stark_fri_num_rounds(domain_length, expansion_factor, num_colinearity_tests)

@@ -58,22 +58,34 @@ class HipEngine:
         return self.ctx.merkle_roots_fe_batch_dev(columns, n, cols, n)
 
     # ---- sharded FRI commit ------------------------------------------------
-    def subtree_roots(self, local: torch.Tensor, chunk_len: int) -> torch.Tensor:
+    def subtree_roots(self, local: torch.Tensor, chunk_len: int, keep: bool = False):
+        """(roots (n_chunks, 32) on the device, forest handle or None)."""
         n_chunks = local.shape[0] // chunk_len
         roots = torch.empty((n_chunks, 32), dtype=torch.uint8, device=local.device)
-        self.ctx.merkle_subtree_roots_dev(local, chunk_len, n_chunks, roots)
-        return roots
+        forest = self.ctx.merkle_subtree_roots_dev(local, chunk_len, n_chunks, roots, keep_forest=keep)
+        return roots, forest
 
-    def root_of_digests(self, digests: torch.Tensor) -> bytes:
-        return self.ctx.merkle_root_of_digests_dev(digests, digests.shape[0])
+    def root_of_digests(self, digests: torch.Tensor, keep: bool = False):
+        """root, or (root, tree handle) with keep."""
+        return self.ctx.merkle_root_of_digests_dev(digests, digests.shape[0], keep_tree=keep)
 
     def fold_shard(self, local: torch.Tensor, alpha: int, offset: int, omega: int, chunk_len: int, period: int,
-                   base: int, want_roots: bool):
+                   base: int, want_roots: bool, keep: bool = False):
+        """(folded share, its chunk roots or None, forest handle or None)."""
         half = local.shape[0] // 2
         out = torch.empty((half, 2), dtype=local.dtype, device=local.device)
         roots = torch.empty((half // chunk_len, 32), dtype=torch.uint8, device=local.device) if want_roots else None
-        self.ctx.fri_fold_shard_dev(local, local.shape[0], alpha, offset, omega, chunk_len, period, base, out, roots)
-        return out, roots
+        forest = self.ctx.fri_fold_shard_dev(local, local.shape[0], alpha, offset, omega, chunk_len, period, base,
+                                             out, roots, keep_forest=keep and want_roots)
+        return out, roots, forest
+
+    def read_elements(self, share: torch.Tensor, local_indices: Sequence[int]) -> List[int]:
+        """Values (as integers) of a few elements of a resident share."""
+        if not local_indices:
+            return []
+        idx = torch.tensor(list(local_indices), dtype=torch.int64, device=share.device)
+        rows = share[idx].cpu().tolist()
+        return [(lo & 0xFFFFFFFFFFFFFFFF) | ((hi & 0xFFFFFFFFFFFFFFFF) << 64) for lo, hi in rows]
 
     def fri_commit(self, codeword: torch.Tensor, offset: int, omega: int, expansion_factor: int,
                    num_colinearity_tests: int, transcript):
@@ -233,14 +245,24 @@ class ShardedFriCommit:
     """Result of fri_commit_sharded: `roots` of all rounds; `shares[k]`, this
     rank's share of layer k for the layers folded shard-wise; `tail`, the
     engine's own commit object for the layers from `len(shares)` on, whole on
-    every rank."""
+    every rank.  With keep_trees also `forests[k]` (this rank's subtrees of
+    layer k) and `tops[k]` (the levels above the subtree roots, on every rank)."""
 
-    def __init__(self, roots, shares, tail, period, chunk_len):
+    def __init__(self, roots, shares, tail, period, chunk_len, n, forests=None, tops=None):
         self.roots: List[bytes] = roots
         self.shares: List[torch.Tensor] = shares
         self.tail = tail
         self.period = period
         self.chunk_len = chunk_len
+        self.n = n
+        self.forests = forests or []
+        self.tops = tops or []
+
+    def free(self):
+        for h in self.forests + self.tops + [self.tail]:
+            if h is not None and hasattr(h, "free"):
+                h.free()
+        self.forests, self.tops = [], []
 
     def gather_layer(self, k: int, group=None) -> torch.Tensor:
         """Layer k < len(shares) in natural order on every rank."""
@@ -251,7 +273,7 @@ class ShardedFriCommit:
 
 def fri_commit_sharded(engine, local: torch.Tensor, n: int, offset: int, omega: int, expansion_factor: int,
                        num_colinearity_tests: int, transcript, period: Optional[int] = None,
-                       group=None) -> ShardedFriCommit:
+                       group=None, keep_trees: bool = False) -> ShardedFriCommit:
     """Fri::commit (fri.rs:100-152) of a length-n codeword of which this rank
     holds `local` = fri_shard_of(codeword, rank, world, period).
 
@@ -275,20 +297,143 @@ def fri_commit_sharded(engine, local: torch.Tensor, n: int, offset: int, omega: 
 
     roots: List[bytes] = []
     shares: List[torch.Tensor] = []
+    forests, tops = [], []
     om, of = omega % P, offset % P
-    chunk_roots = engine.subtree_roots(local, c) if sharded_rounds else None
+    chunk_roots, forest = engine.subtree_roots(local, c, keep=keep_trees) if sharded_rounds else (None, None)
     for k in range(sharded_rounds):
         g = _all_gather(chunk_roots, group)                             # [rank][q]; chunk q*world + rank of the layer
         digests = g.permute(1, 0, 2).reshape(-1, 32).contiguous()
-        root = engine.root_of_digests(digests)                          # fri.rs:119
+        if keep_trees:
+            root, top = engine.root_of_digests(digests, keep=True)      # fri.rs:119
+            forests.append(forest)
+            tops.append(top)
+        else:
+            root = engine.root_of_digests(digests)
         roots.append(root)
         alpha = transcript(k, False, root)                              # fri.rs:120,126-127
         shares.append(local)
-        local, chunk_roots = engine.fold_shard(local, alpha, of, om, c, period, rank * c,
-                                               want_roots=k + 1 < sharded_rounds)   # fri.rs:133-139
+        local, chunk_roots, forest = engine.fold_shard(local, alpha, of, om, c, period, rank * c,
+                                                       want_roots=k + 1 < sharded_rounds, keep=keep_trees)  # fri.rs:133-139
         om, of = om * om % P, of * of % P                               # fri.rs:141-142
     whole = _all_gather(local, group).reshape(period, 2)                # one chunk per rank: the layer in order
     tail = engine.fri_commit(whole, of, om, expansion_factor, num_colinearity_tests,
                              lambda r, last, root: transcript(sharded_rounds + r, last, root))
     roots.extend(tail.root(i) for i in range(len(tail)))
-    return ShardedFriCommit(roots, shares, tail, period, c)
+    return ShardedFriCommit(roots, shares, tail, period, c, n, forests, tops)
+
+
+# ---- the query phase on the sharded layers ----------------------------------
+def _u32_digits(v: int) -> List[int]:
+    d = []
+    while v:
+        d.append(v & 0xFFFFFFFF)
+        v >>= 32
+    return d
+
+
+def json_field_vec(values: Sequence[int]) -> str:
+    """serde_json::to_string(&Vec<FieldElement>) (fri.rs:146): BigInt as [sign, u32 digits low first]."""
+    return "[" + ",".join('{"value":[%d,[%s]]}' % (0 if v == 0 else 1, ",".join(map(str, _u32_digits(v))))
+                          for v in values) + "]"
+
+
+def json_hash_path(path: Sequence[bytes]) -> str:
+    """serde_json::to_string(&Vec<HashOutput>) (fri.rs:188)."""
+    return "[" + ",".join("[" + ",".join(str(b) for b in h) + "]" for h in path) + "]"
+
+
+def fri_sample_indices(seed: bytes, size: int, reduced_size: int, number: int) -> List[int]:
+    """Fri::sample_indices / sample_index (fri.rs:54-87): BLAKE2b-512(seed || counter u64 LE), folded
+    big-endian into a usize (the last eight bytes survive), mod size; distinct modulo reduced_size."""
+    import hashlib
+    indices: List[int] = []
+    reduced: List[int] = []
+    counter = 0
+    while len(indices) < number:
+        h = hashlib.blake2b(seed + counter.to_bytes(8, "little"), digest_size=64).digest()
+        index = int.from_bytes(h[-8:], "big") % size
+        counter += 1
+        if index % reduced_size not in reduced:
+            indices.append(index)
+            reduced.append(index % reduced_size)
+    return indices
+
+
+def _sharded_openings(engine, commit: ShardedFriCommit, layer: int, positions: Sequence[int], rank: int, world: int,
+                      group):
+    """Values and authentication paths of `positions` in sharded layer `layer`, on every rank: the
+    owner of a position reads the element and the siblings inside its subtree; those travel in one
+    zero-padded all-reduce (non-owners contribute zeros); the upper siblings come from the
+    replicated top levels."""
+    c, period = commit.chunk_len, commit.period
+    sub_levels = c.bit_length() - 1
+    slot = 16 + 32 * sub_levels
+    buf = torch.zeros((len(positions), slot), dtype=torch.uint8)
+    mine = [(s, (i // period) * c + i % c) for s, i in enumerate(positions) if (i % period) // c == rank]
+    vals = engine.read_elements(commit.shares[layer], [l for _, l in mine])
+    for (s, l), v in zip(mine, vals):
+        raw = v.to_bytes(16, "little") + b"".join(commit.forests[layer].open(l))
+        buf[s] = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
+    if world > 1:
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else buf.device
+        t = buf.to(torch.int32).to(dev)                  # byte sums of one owner and zeros: exact in any integer type
+        dist.all_reduce(t, group=group)
+        buf = t.cpu().to(torch.uint8)
+    out = []
+    for s, i in enumerate(positions):
+        raw = bytes(buf[s].tolist())
+        value = int.from_bytes(raw[:16], "little")
+        path = [raw[16 + 32 * j:48 + 32 * j] for j in range(sub_levels)] + commit.tops[layer].open(i // c)
+        out.append((value, path))
+    return out
+
+
+def fri_prove_sharded(engine, local: torch.Tensor, n: int, offset: int, omega: int, expansion_factor: int,
+                      num_colinearity_tests: int, stream, period: Optional[int] = None, group=None) -> List[int]:
+    """Fri::prove (fri.rs:212-254) of a codeword dealt out over the ranks as in
+    fri_commit_sharded.  `stream` is this rank's copy of the proof stream
+    (push(str), fiat_shamir(nbytes) -> bytes, as proof_stream.rs:23-58); every
+    rank ends with the same stream, byte for byte the single-GPU one.  Returns
+    the first round's a and b indices."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    t = num_colinearity_tests
+
+    def transcript(rnd, last, root):
+        stream.push(root.hex())                                         # fri.rs:120
+        return None if last else int.from_bytes(stream.fiat_shamir(32), "big") % P   # fri.rs:126-127, field.rs:110-116
+
+    commit = fri_commit_sharded(engine, local, n, offset, omega, expansion_factor, t, transcript, period, group,
+                                keep_trees=True)
+    try:
+        k_sh, tail = len(commit.shares), commit.tail
+        rounds = k_sh + len(tail)
+        last_len = n >> (rounds - 1)
+        last_raw = tail.download(len(tail) - 1)
+        stream.push(json_field_vec([int(lo) | (int(hi) << 64) for lo, hi in last_raw.tolist()]))    # fri.rs:146
+        top = fri_sample_indices(stream.fiat_shamir(32), n // 2, last_len, t)                      # fri.rs:218-223
+
+        def openings(layer, positions):
+            if layer < k_sh:
+                return _sharded_openings(engine, commit, layer, positions, rank, world, group)
+            vals = tail.read(layer - k_sh, positions)
+            return [(int(lo) | (int(hi) << 64), tail.open(layer - k_sh, i))
+                    for (lo, hi), i in zip(vals.tolist(), positions)]
+
+        indices = list(top)
+        for i in range(rounds - 1):                                     # fri.rs:228-242
+            half = (n >> i) // 2
+            cs = [idx % half for idx in indices][:t]
+            a, b = cs, [x + half for x in cs]
+            cur = openings(i, a + b)
+            nxt = openings(i + 1, cs)
+            for s in range(t):                                          # fri.rs:166-179
+                stream.push('["%d","%d","%d"]' % (cur[s][0], cur[t + s][0], nxt[s][0]))
+            for s in range(t):                                          # fri.rs:182-204
+                stream.push(json_hash_path(cur[s][1]))
+                stream.push(json_hash_path(cur[t + s][1]))
+                stream.push(json_hash_path(nxt[s][1]))
+            indices = a + b
+        return list(top) + [x + n // 2 for x in top]                    # fri.rs:246-253
+    finally:
+        commit.free()

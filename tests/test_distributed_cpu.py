@@ -54,20 +54,41 @@ class OracleEngine:
     def merkle_root(self, column):
         return self.oc.merkle_commit_fe(np.ascontiguousarray(column.numpy().view(np.uint64)))
 
-    # ---- sharded FRI commit ------------------------------------------------
-    def subtree_roots(self, local, chunk_len):
-        a = local.numpy().view(np.uint64)
-        roots = [self.oc.merkle_commit_fe(np.ascontiguousarray(a[i:i + chunk_len]))
-                 for i in range(0, a.shape[0], chunk_len)]
-        return torch.from_numpy(np.frombuffer(b"".join(roots), dtype=np.uint8).reshape(-1, 32).copy())
+    # ---- sharded FRI commit / prove ----------------------------------------
+    class _Levels:
+        """Levels of digests (leaf level first) with Merkle::open's sibling walk (merkle.rs:54-93)."""
 
-    def root_of_digests(self, digests):
-        level = [bytes(d.tolist()) for d in digests]
-        while len(level) > 1:                                  # merkle.rs:38-51 pairs (2i, 2i+1)
+        def __init__(self, levels, n_levels):
+            self.levels, self.n_levels = levels, n_levels
+
+        def open(self, index):
+            return [self.levels[k][(index >> k) ^ 1] for k in range(self.n_levels)]
+
+        def free(self):
+            pass
+
+    def _reduce(self, level, n_levels):
+        levels = [level]
+        for _ in range(n_levels):                              # merkle.rs:38-51 pairs (2i, 2i+1)
             level = [self.oc.blake2b(level[i] + level[i + 1]) for i in range(0, len(level), 2)]
-        return level[0]
+            levels.append(level)
+        return levels
 
-    def fold_shard(self, local, alpha, offset, omega, chunk_len, period, base, want_roots):
+    def subtree_roots(self, local, chunk_len, keep=False):
+        a = self.oc.to_ints(local.numpy().view(np.uint64))
+        leaves = [self.oc.blake2b(self.oc.bincode_fe(v)) for v in a]
+        n_levels = chunk_len.bit_length() - 1
+        levels = self._reduce(leaves, n_levels)
+        roots = torch.from_numpy(np.frombuffer(b"".join(levels[-1]), dtype=np.uint8).reshape(-1, 32).copy())
+        return roots, (self._Levels(levels, n_levels) if keep else None)
+
+    def root_of_digests(self, digests, keep=False):
+        level = [bytes(d.tolist()) for d in digests]
+        n_levels = len(level).bit_length() - 1
+        levels = self._reduce(level, n_levels)
+        return (levels[-1][0], self._Levels(levels, n_levels)) if keep else levels[-1][0]
+
+    def fold_shard(self, local, alpha, offset, omega, chunk_len, period, base, want_roots, keep=False):
         so, oc = self.so, self.oc
         a = oc.to_ints(local.numpy().view(np.uint64))
         half = len(a) // 2
@@ -79,14 +100,20 @@ class OracleEngine:
             out.append(so.fe_mul(two_inv, so.fe_add(so.fe_mul(so.fe_add(1, r), a[l]),
                                                     so.fe_mul(so.fe_sub(1, r), a[half + l]))))
         t = torch.from_numpy(oc.from_ints(out).view(np.int64))
-        return t, (self.subtree_roots(t, chunk_len) if want_roots else None)
+        roots, forest = self.subtree_roots(t, chunk_len, keep) if want_roots else (None, None)
+        return t, roots, forest
+
+    def read_elements(self, share, local_indices):
+        a = share.numpy().view(np.uint64)
+        return [self.oc.to_int(a[l]) for l in local_indices]
 
     def fri_commit(self, codeword, offset, omega, expansion, ncol, transcript):
         so, oc = self.so, self.oc
         cw = np.ascontiguousarray(codeword.numpy().view(np.uint64))
         rounds = oc.lib.so_fri_num_rounds(cw.shape[0], expansion, ncol)
-        layers, roots = [], []
+        layers, roots, trees = [], [], []
         for r in range(rounds):
+            trees.append(oc.merkle_tree_fe(cw))
             root = oc.merkle_commit_fe(cw)
             roots.append(root)
             layers.append(cw)
@@ -102,6 +129,18 @@ class OracleEngine:
 
             def root(self, i):
                 return roots[i]
+
+            def download(self, i):
+                return layers[i]
+
+            def read(self, i, idx):
+                return layers[i][list(idx)]
+
+            def open(self, i, index):
+                return oc.merkle_open(trees[i], index)
+
+            def free(self):
+                pass
         tail = Tail()
         tail.layers = layers
         return tail
@@ -142,6 +181,66 @@ def _fri_worker(rank, world, port, log_n, period, q):
         q.put((rank, ok, k_sh))
     finally:
         dist.destroy_process_group()
+
+
+def _fri_prove_worker(rank, world, port, log_n, period, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sys.path.insert(0, ROOT)
+        from stark_amd import distributed as D
+        eng = OracleEngine()
+        oc, so = eng.oc, eng.so
+        n, expansion, ncol = 1 << log_n, 4, 3
+        # a codeword FRI accepts: evaluations of a polynomial of degree < n/expansion on the coset
+        coeffs = oc.splitmix(n // expansion, 321)
+        omega, offset = so.primitive_nth_root(n), so.GENERATOR
+        x = oc.coset_lde(coeffs, n, offset)
+        ref_stream = so.ProofStream()
+        fri = so.Fri(offset, omega, n, expansion, ncol)
+        ref_indices = fri.prove(oc.to_ints(x), ref_stream)
+        used = D.fri_shard_period(n, world, expansion, ncol, period)
+        local = D.fri_shard_of(torch.from_numpy(x.view(np.int64)), rank, world, used)
+
+        class Stream:                                          # proof_stream.rs:23-58
+            def __init__(self):
+                self.ps = so.ProofStream()
+
+            def push(self, s):
+                self.ps.push(s)
+
+            def fiat_shamir(self, nbytes):
+                return self.ps.prover_fiat_shamir(nbytes)
+        stream = Stream()
+        indices = D.fri_prove_sharded(eng, local, n, offset, omega, expansion, ncol, stream, period=period)
+        same = stream.ps.objects == ref_stream.objects and indices == ref_indices
+        # and the reference verifier's restatement accepts the stream
+        ver = so.ProofStream.deserialize(stream.ps.serialize())
+        accepted = fri.verify(ver, [])
+        q.put((rank, bool(same), bool(accepted)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,log_n,period", [(2, 9, 32), (4, 10, 16), (2, 7, None)])
+def test_fri_prove_sharded_gloo(world, log_n, period):
+    """The proof stream of the sharded Fri::prove equals the single-vector one
+    object for object (roots, last codeword, colinearity triples, paths put
+    together from an owner's subtree and the shared top levels), on every rank."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000) + world * 13 + log_n
+    procs = [ctx.Process(target=_fri_prove_worker, args=(r, world, port, log_n, period, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, same, accepted in results:
+        assert same, f"rank {rank}: proof stream differs from the single-vector prover's"
+        assert accepted, f"rank {rank}: verifier rejected"
 
 
 @pytest.mark.parametrize("world,log_n,period,sharded", [(2, 10, 64, 4), (2, 9, None, 0), (4, 10, 4, 6), (2, 8, 2, 4)])

@@ -179,3 +179,61 @@ def test_fri_commit_sharded_two_ranks_one_gpu():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sorted(results) == [(0, True), (1, True)]
+
+
+def _fri_prove_two_rank_worker(rank, world, port, q):
+    import sys
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        here = os.path.dirname(os.path.abspath(__file__))
+        for p in (os.path.dirname(here), here, os.path.join(os.path.dirname(here), "oracle")):
+            if p not in sys.path:
+                sys.path.insert(0, p)
+        import oracle_c
+        import stark_oracle
+        from stark_amd import Context, hostlib
+        from stark_amd.distributed import HipEngine, fri_prove_sharded, fri_shard_of, fri_shard_period
+        torch.cuda.set_device(0)
+        ctx = Context(0)
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        eng = HipEngine(ctx)
+        n, expansion, ncol = 1 << 13, 4, 5
+        coeffs = oracle_c.splitmix(n // expansion, 654)
+        omega, offset = stark_oracle.primitive_nth_root(n), stark_oracle.GENERATOR
+        x = oracle_c.coset_lde(coeffs, n, offset)
+        ref_stream = stark_oracle.ProofStream()
+        fri = stark_oracle.Fri(offset, omega, n, expansion, ncol)
+        ref_indices = fri.prove(oracle_c.to_ints(x), ref_stream)
+        period = fri_shard_period(n, world, expansion, ncol, 1 << 8)
+        local = fri_shard_of(torch.from_numpy(x.view(np.int64)), rank, world, period).cuda()
+        stream = hostlib.Stream()                       # the C++ ProofStream of the host mirror
+        indices = fri_prove_sharded(eng, local, n, offset, omega, expansion, ncol, stream, period=1 << 8)
+        torch.cuda.synchronize()
+        same = list(stream.objects) == ref_stream.objects and indices == ref_indices
+        accepted = fri.verify(stark_oracle.ProofStream.deserialize(stream.serialize()), [])
+        ctx.close()
+        q.put((rank, bool(same), bool(accepted)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_fri_prove_sharded_two_ranks_one_gpu():
+    """Sharded Fri::prove with the HIP engine on two processes sharing the GPU:
+    the proof stream equals the single-vector prover's restatement object for
+    object and its verifier accepts."""
+    import torch.multiprocessing as mp
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    port = 30900 + os.getpid() % 1000
+    procs = [mpc.Process(target=_fri_prove_two_rank_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=280) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(results) == [(0, True, True), (1, True, True)]

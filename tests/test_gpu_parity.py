@@ -469,3 +469,49 @@ def test_one_context_from_several_threads(ctx):
     for t in threads:
         t.join(timeout=120)
     assert not errors, errors
+
+
+@pytest.mark.parametrize("chunk_len,n_chunks", [(1, 4), (8, 2), (256, 16), (1 << 12, 8)])
+def test_forest_and_top_tree_give_whole_paths(ctx, chunk_len, n_chunks):
+    """Siblings inside a chunk's subtree (kept forest) followed by the siblings
+    above its root (kept top tree) are Merkle::open's path in the whole tree."""
+    import torch
+    from stark_amd import StarkError
+    n = chunk_len * n_chunks
+    x = oc.splitmix(n, 900 + n_chunks)
+    d = torch.from_numpy(x.view(np.int64)).cuda()
+    roots = torch.empty((n_chunks, 32), dtype=torch.uint8, device="cuda")
+    forest = ctx.merkle_subtree_roots_dev(d, chunk_len, n_chunks, roots, keep_forest=True)
+    root, top = ctx.merkle_root_of_digests_dev(roots, n_chunks, keep_tree=True)
+    tree = oc.merkle_tree_fe(x)
+    assert root == oc.merkle_commit_fe(x)
+    for i in sorted({0, 1 % n, n // 2, n - 1, (n // 3) | 1 if n > 2 else 0}):
+        assert forest.open(i) + top.open(i // chunk_len) == oc.merkle_open(tree, i)
+    if chunk_len > 1 and n_chunks > 1:
+        with pytest.raises(StarkError, match="forest"):
+            forest.download()
+    forest.free()
+    top.free()
+
+
+def test_fold_shard_keeps_forest(ctx):
+    import torch
+    from stark_amd.distributed import fri_shard_of
+    n, world, period, rank = 1 << 12, 4, 256, 2
+    c = period // world
+    x = oc.splitmix(n, 950)
+    alpha = oc.to_int(oc.splitmix(1, 10)[0])
+    omega, offset = so.primitive_nth_root(n), so.GENERATOR
+    ref = oc.fri_fold(x, alpha, offset, omega)
+    tree = oc.merkle_tree_fe(ref)
+    local = fri_shard_of(torch.from_numpy(x.view(np.int64)), rank, world, period).cuda()
+    out = torch.empty((local.shape[0] // 2, 2), dtype=torch.int64, device="cuda")
+    roots = torch.empty((out.shape[0] // c, 32), dtype=torch.uint8, device="cuda")
+    forest = ctx.fri_fold_shard_dev(local, local.shape[0], alpha, offset, omega, c, period, rank * c, out, roots,
+                                    keep_forest=True)
+    ctx.synchronize()
+    sub = c.bit_length() - 1
+    for l in (0, 5, out.shape[0] - 1):
+        pos = (l // c) * period + rank * c + l % c
+        assert forest.open(l) == oc.merkle_open(tree, pos)[:sub]
+    forest.free()
