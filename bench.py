@@ -275,7 +275,7 @@ def main():
                         ser = len(objs).to_bytes(8, "little") + b"".join(
                             len(o).to_bytes(8, "little") + o.encode() for o in objs)
                         return int.from_bytes(hashlib.shake_256(ser).digest(32), "big") % ((407 << 119) + 1)
-                    fri_commit_sharded(eng, share, n24, GENERATOR, w24, 4, 17, transcript).tail.free()
+                    fri_commit_sharded(eng, share, n24, GENERATOR, w24, 4, 17, transcript).free()
 
                 fri_sharded_once()
                 barrier()

@@ -1,0 +1,31 @@
+"""Wall-clock of the host-pointer entry points (pageable numpy memory in and out, PCIe included).
+usage: python3 tools/host_api_time.py"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+
+from stark_amd import Context
+from stark_amd.synth import field_vector
+
+ctx = Context(0)
+for log_n in (20, 22, 24):
+    n = 1 << log_n
+    x = field_vector(n, log_n)
+    ctx.ntt(x)
+    t0 = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        ctx.ntt(x)
+    dt = (time.perf_counter() - t0) / reps
+    ctx.merkle_commit_fe(x)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ctx.merkle_commit_fe(x)
+    dm = (time.perf_counter() - t0) / reps
+    print("2^%d: stark_ntt %.2f ms (%.1f GB/s over both directions), stark_merkle_commit_fe %.2f ms (%.1f GB/s in)"
+          % (log_n, dt * 1e3, 32 * n / dt / 1e9, dm * 1e3, 16 * n / dm / 1e9))
+ctx.close()
