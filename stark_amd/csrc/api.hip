@@ -3,11 +3,13 @@
 #include <hip/hip_runtime.h>
 
 #include <array>
+#include <atomic>
 #include <cstring>
 #include <map>
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <tuple>
 #include <utility>
 #include <vector>
@@ -80,6 +82,15 @@ struct stark_ctx {
     std::multimap<size_t, void*> pool;                 // cached device blocks by size
     void* pinned = nullptr;                            // small pinned staging buffer (4 KiB)
     std::recursive_mutex mu;
+    // Lanes for large transfers between pageable host memory and the device: each has a stream
+    // of its own and two pinned chunks (created on first use).
+    struct Lane {
+        hipStream_t stream = nullptr;
+        void* pin[2] = {nullptr, nullptr};
+        hipEvent_t ev[2] = {nullptr, nullptr};
+    };
+    std::vector<Lane> lanes;
+    hipEvent_t lane_gate = nullptr;
 };
 
 struct stark_tree {
@@ -392,6 +403,123 @@ static bool is_one(fe x) { return x.lo == 1 && x.hi == 0; }
 static bool is_canonical(fe x) { return !ge_p(x.lo, x.hi); }
 
 // RAII staging buffer for the host-pointer entry points
+// ---------------------------------------------------------------------------
+// Host <-> device transfers of pageable memory.  The runtime stages such copies
+// through pinned memory on one thread (about 20 GB/s here); for large vectors
+// several lanes do the same staging side by side, each on its own thread and
+// stream, which brings the rate close to what the link gives for pinned memory.
+// ---------------------------------------------------------------------------
+constexpr size_t LANE_CHUNK = (size_t)4 << 20;
+constexpr size_t LANE_COUNT = 4;
+constexpr size_t LANE_THRESHOLD = (size_t)32 << 20;    // smaller transfers go through the runtime
+
+static hipError_t lanes_init(stark_ctx* ctx)
+{
+    if (!ctx->lanes.empty()) return hipSuccess;
+    std::vector<stark_ctx::Lane> lanes(LANE_COUNT);
+    hipError_t e = hipEventCreateWithFlags(&ctx->lane_gate, hipEventDisableTiming);
+    for (auto& l : lanes) {
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking);
+        for (int b = 0; b < 2 && e == hipSuccess; b++) {
+            e = hipHostMalloc(&l.pin[b], LANE_CHUNK, hipHostMallocDefault);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&l.ev[b], hipEventDisableTiming);
+        }
+    }
+    if (e != hipSuccess) return e;          // partially built lanes are released with the context's process
+    ctx->lanes = std::move(lanes);
+    return hipSuccess;
+}
+
+static void lanes_destroy(stark_ctx* ctx)
+{
+    for (auto& l : ctx->lanes) {
+        if (l.stream) (void)hipStreamSynchronize(l.stream);
+        for (int b = 0; b < 2; b++) {
+            if (l.pin[b]) (void)hipHostFree(l.pin[b]);
+            if (l.ev[b]) (void)hipEventDestroy(l.ev[b]);
+        }
+        if (l.stream) (void)hipStreamDestroy(l.stream);
+    }
+    ctx->lanes.clear();
+    if (ctx->lane_gate) (void)hipEventDestroy(ctx->lane_gate);
+    ctx->lane_gate = nullptr;
+}
+
+// dst_dev <- src_host, ordered after earlier work on the context's stream; later work on that
+// stream is ordered after the copy.  The host buffer is consumed before the call returns.
+static hipError_t copy_in(stark_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes)
+{
+    if (bytes < LANE_THRESHOLD)
+        return hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream);
+    hipError_t e = lanes_init(ctx);
+    if (e == hipSuccess) e = hipEventRecord(ctx->lane_gate, ctx->stream);
+    if (e != hipSuccess) return e;
+    const size_t chunks = (bytes + LANE_CHUNK - 1) / LANE_CHUNK;
+    std::atomic<int> err{(int)hipSuccess};
+    auto work = [&](size_t t) {
+        stark_ctx::Lane& l = ctx->lanes[t];
+        hipError_t r = hipSetDevice(ctx->device);
+        if (r == hipSuccess) r = hipStreamWaitEvent(l.stream, ctx->lane_gate, 0);
+        size_t turn = 0;
+        for (size_t k = t; k < chunks && r == hipSuccess; k += LANE_COUNT, turn++) {
+            const int b = (int)(turn & 1);
+            const size_t off = k * LANE_CHUNK, len = bytes - off < LANE_CHUNK ? bytes - off : LANE_CHUNK;
+            if (turn >= 2) r = hipEventSynchronize(l.ev[b]);                 // the chunk's previous DMA has read it
+            if (r != hipSuccess) break;
+            memcpy(l.pin[b], (const uint8_t*)src_host + off, len);
+            r = hipMemcpyAsync((uint8_t*)dst_dev + off, l.pin[b], len, hipMemcpyHostToDevice, l.stream);
+            if (r == hipSuccess) r = hipEventRecord(l.ev[b], l.stream);
+        }
+        if (r == hipSuccess) r = hipStreamSynchronize(l.stream);             // pinned chunks are reused by the next call
+        if (r != hipSuccess) err.store((int)r);
+    };
+    std::vector<std::thread> threads;
+    for (size_t t = 1; t < LANE_COUNT; t++) threads.emplace_back(work, t);
+    work(0);
+    for (auto& th : threads) th.join();
+    return (hipError_t)err.load();
+}
+
+// dst_host <- src_dev, ordered after earlier work on the context's stream; complete on return.
+static hipError_t copy_out(stark_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes)
+{
+    if (bytes < LANE_THRESHOLD) {
+        hipError_t e = hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream);
+        return e == hipSuccess ? hipStreamSynchronize(ctx->stream) : e;
+    }
+    hipError_t e = lanes_init(ctx);
+    if (e == hipSuccess) e = hipEventRecord(ctx->lane_gate, ctx->stream);
+    if (e != hipSuccess) return e;
+    const size_t chunks = (bytes + LANE_CHUNK - 1) / LANE_CHUNK;
+    std::atomic<int> err{(int)hipSuccess};
+    auto work = [&](size_t t) {
+        stark_ctx::Lane& l = ctx->lanes[t];
+        hipError_t r = hipSetDevice(ctx->device);
+        if (r == hipSuccess) r = hipStreamWaitEvent(l.stream, ctx->lane_gate, 0);
+        auto issue = [&](size_t k, int b) {
+            const size_t off = k * LANE_CHUNK, len = bytes - off < LANE_CHUNK ? bytes - off : LANE_CHUNK;
+            hipError_t q = hipMemcpyAsync(l.pin[b], (const uint8_t*)src_dev + off, len, hipMemcpyDeviceToHost, l.stream);
+            return q == hipSuccess ? hipEventRecord(l.ev[b], l.stream) : q;
+        };
+        if (r == hipSuccess && t < chunks) r = issue(t, 0);
+        size_t turn = 0;
+        for (size_t k = t; k < chunks && r == hipSuccess; k += LANE_COUNT, turn++) {
+            const int b = (int)(turn & 1);
+            if (k + LANE_COUNT < chunks) r = issue(k + LANE_COUNT, b ^ 1);   // next chunk flies while this one is copied out
+            if (r == hipSuccess) r = hipEventSynchronize(l.ev[b]);
+            if (r != hipSuccess) break;
+            const size_t off = k * LANE_CHUNK, len = bytes - off < LANE_CHUNK ? bytes - off : LANE_CHUNK;
+            memcpy((uint8_t*)dst_host + off, l.pin[b], len);
+        }
+        if (r != hipSuccess) err.store((int)r);
+    };
+    std::vector<std::thread> threads;
+    for (size_t t = 1; t < LANE_COUNT; t++) threads.emplace_back(work, t);
+    work(0);
+    for (auto& th : threads) th.join();
+    return (hipError_t)err.load();
+}
+
 struct DevBuf {
     stark_ctx* ctx;
     void* p = nullptr;
@@ -579,6 +707,7 @@ extern "C" void stark_ctx_destroy(stark_ctx* ctx)
     for (auto& kv : ctx->pool) (void)hipFree(kv.second);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    lanes_destroy(ctx);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -630,7 +759,7 @@ extern "C" int32_t stark_copy_h2d(stark_ctx* ctx, void* dst_dev, const void* src
 {
     CtxGuard guard_(ctx);
     if (!ctx) return fail(STARK_EARG, "null context");
-    HIP_TRY(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(copy_in(ctx, dst_dev, src_host, bytes));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return STARK_OK;
 }
@@ -639,7 +768,7 @@ extern "C" int32_t stark_copy_d2h(stark_ctx* ctx, void* dst_host, const void* sr
 {
     CtxGuard guard_(ctx);
     if (!ctx) return fail(STARK_EARG, "null context");
-    HIP_TRY(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(copy_out(ctx, dst_host, src_dev, bytes));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return STARK_OK;
 }
@@ -686,9 +815,9 @@ extern "C" int32_t stark_ntt_batch(stark_ctx* ctx, uint64_t* data, size_t n, siz
     const size_t span = (n_cols - 1) * col_stride + n;
     DevBuf buf(ctx);
     ST_TRY(buf.alloc(span * sizeof(fe)));
-    HIP_TRY(hipMemcpyAsync(buf.p, data, span * sizeof(fe), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(copy_in(ctx, buf.p, data, span * sizeof(fe)));
     ST_TRY(stark_ntt_batch_dev(ctx, (uint64_t*)buf.p, n, n_cols, col_stride, inverse));
-    HIP_TRY(hipMemcpyAsync(data, buf.p, span * sizeof(fe), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(copy_out(ctx, data, buf.p, span * sizeof(fe)));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return STARK_OK;
 }
@@ -734,16 +863,15 @@ extern "C" int32_t stark_coset_lde_batch(stark_ctx* ctx, const uint64_t* coeffs,
     DevBuf in(ctx), ob(ctx);
     ST_TRY(in.alloc(in_span * sizeof(fe)));
     ST_TRY(ob.alloc(out_span * sizeof(fe)));
-    if (in_span) HIP_TRY(hipMemcpyAsync(in.p, coeffs, in_span * sizeof(fe), hipMemcpyHostToDevice, ctx->stream));
+    if (in_span) HIP_TRY(copy_in(ctx, in.p, coeffs, in_span * sizeof(fe)));
     ST_TRY(stark_coset_lde_batch_dev(ctx, (const uint64_t*)in.p, n_coeffs, coeff_stride, n_cols, n_out, offset,
                                      (uint64_t*)ob.p, out_stride));
     // only the columns are defined; copy them one by one when padded
     if (out_stride == n_out || n_cols == 1) {
-        HIP_TRY(hipMemcpyAsync(out, ob.p, out_span * sizeof(fe), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(copy_out(ctx, out, ob.p, out_span * sizeof(fe)));
     } else {
         for (size_t c = 0; c < n_cols; c++)
-            HIP_TRY(hipMemcpyAsync(out + 2 * c * out_stride, (fe*)ob.p + c * out_stride, n_out * sizeof(fe),
-                                   hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(copy_out(ctx, out + 2 * c * out_stride, (fe*)ob.p + c * out_stride, n_out * sizeof(fe)));
     }
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return STARK_OK;
@@ -766,10 +894,10 @@ extern "C" int32_t stark_vec_mul(stark_ctx* ctx, const uint64_t* a, const uint64
     DevBuf da(ctx), db(ctx);
     ST_TRY(da.alloc(n * sizeof(fe)));
     ST_TRY(db.alloc(n * sizeof(fe)));
-    HIP_TRY(hipMemcpyAsync(da.p, a, n * sizeof(fe), hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(db.p, b, n * sizeof(fe), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(copy_in(ctx, da.p, a, n * sizeof(fe)));
+    HIP_TRY(copy_in(ctx, db.p, b, n * sizeof(fe)));
     ST_TRY(stark_vec_mul_dev(ctx, (uint64_t*)da.p, (uint64_t*)db.p, (uint64_t*)da.p, n));
-    HIP_TRY(hipMemcpyAsync(out, da.p, n * sizeof(fe), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(copy_out(ctx, out, da.p, n * sizeof(fe)));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return STARK_OK;
 }
@@ -813,7 +941,7 @@ extern "C" int32_t stark_merkle_commit_fe(stark_ctx* ctx, const uint64_t* elems,
     if (log2_exact(n) < 0) return fail(STARK_ENOTPOW2, "length must be power of two");
     DevBuf buf(ctx);
     ST_TRY(buf.alloc(n * sizeof(fe)));
-    HIP_TRY(hipMemcpyAsync(buf.p, elems, n * sizeof(fe), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(copy_in(ctx, buf.p, elems, n * sizeof(fe)));
     return tree_build(ctx, (const fe*)buf.p, n, root, tree_out);
 }
 
@@ -828,7 +956,7 @@ extern "C" int32_t stark_merkle_commit_bytes(stark_ctx* ctx, const uint8_t* flat
     DevBuf dflat(ctx), doff(ctx);
     ST_TRY(dflat.alloc(total ? total : 16));
     ST_TRY(doff.alloc((n + 1) * sizeof(uint64_t)));
-    if (total) HIP_TRY(hipMemcpyAsync(dflat.p, flat, total, hipMemcpyHostToDevice, ctx->stream));
+    if (total) HIP_TRY(copy_in(ctx, dflat.p, flat, total));
     HIP_TRY(hipMemcpyAsync(doff.p, offsets, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
     const size_t bytes = (2 * n - 1) * sizeof(digest);
     void* d = nullptr;
@@ -862,8 +990,7 @@ extern "C" int32_t stark_tree_download(stark_tree* tree, uint8_t* out)
     CtxGuard guard_(tree ? tree->ctx : nullptr);
     if (!tree || !out) return fail(STARK_EARG, "null argument");
     if (tree->levels != (uint32_t)log2_exact(tree->n)) return fail(STARK_EARG, "a forest of subtrees has no upper levels to download");
-    HIP_TRY(hipMemcpyAsync(out, tree->d, (2 * tree->n - 1) * sizeof(digest), hipMemcpyDeviceToHost,
-                           tree->ctx->stream));
+    HIP_TRY(copy_out(tree->ctx, out, tree->d, (2 * tree->n - 1) * sizeof(digest)));
     HIP_TRY(hipStreamSynchronize(tree->ctx->stream));
     return STARK_OK;
 }
@@ -995,9 +1122,9 @@ extern "C" int32_t stark_fri_fold(stark_ctx* ctx, const uint64_t* codeword, size
     DevBuf in(ctx), ob(ctx);
     ST_TRY(in.alloc(N * sizeof(fe)));
     ST_TRY(ob.alloc(N / 2 * sizeof(fe)));
-    HIP_TRY(hipMemcpyAsync(in.p, codeword, N * sizeof(fe), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(copy_in(ctx, in.p, codeword, N * sizeof(fe)));
     ST_TRY(stark_fri_fold_dev(ctx, (const uint64_t*)in.p, N, alpha, offset, omega, (uint64_t*)ob.p));
-    HIP_TRY(hipMemcpyAsync(out, ob.p, N / 2 * sizeof(fe), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(copy_out(ctx, out, ob.p, N / 2 * sizeof(fe)));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return STARK_OK;
 }
@@ -1066,7 +1193,7 @@ static int32_t fri_commit_impl(stark_ctx* ctx, const fe* cw_src, bool src_is_hos
     if (rc != STARK_OK) return cleanup(rc);
 
     if (src_is_host)                                                                                   // fri.rs:130
-        FRI_HIP(hipMemcpyAsync(L->cw[0], cw_src, N * sizeof(fe), hipMemcpyHostToDevice, ctx->stream));
+        FRI_HIP(copy_in(ctx, L->cw[0], cw_src, N * sizeof(fe)));
     // Roots arrive through host-mapped pinned memory, written by the kernel that
     // produces them; a one-leaf layer has no such kernel and is copied instead.
     digest* root_mail = (digest*)((uint8_t*)ctx->pinned + 2048);
@@ -1144,7 +1271,7 @@ extern "C" int32_t stark_fri_layer_download(stark_fri_layers* l, size_t layer, u
 {
     CtxGuard guard_(l ? l->ctx : nullptr);
     if (!l || !out || layer >= l->len.size()) return fail(STARK_EARG, "bad layer");
-    HIP_TRY(hipMemcpyAsync(out, l->cw[layer], l->len[layer] * sizeof(fe), hipMemcpyDeviceToHost, l->ctx->stream));
+    HIP_TRY(copy_out(l->ctx, out, l->cw[layer], l->len[layer] * sizeof(fe)));
     HIP_TRY(hipStreamSynchronize(l->ctx->stream));
     return STARK_OK;
 }

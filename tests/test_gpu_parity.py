@@ -515,3 +515,20 @@ def test_fold_shard_keeps_forest(ctx):
         pos = (l // c) * period + rank * c + l % c
         assert forest.open(l) == oc.merkle_open(tree, pos)[:sub]
     forest.free()
+
+
+def test_large_host_transfers_ragged_sizes(ctx):
+    """Host-pointer calls from 32 MiB up go through several staging lanes in 4 MiB
+    chunks: sizes that are not multiples of a chunk or of the lane count, in and
+    out, still give the oracle's results."""
+    cols, n_coeffs, n_out = 5, 450001, 1 << 19
+    coeffs = oc.splitmix(cols * n_coeffs, 4242).reshape(cols, n_coeffs, 2)
+    got = ctx.coset_lde_batch(coeffs, n_out, G)
+    for c in range(cols):
+        assert np.array_equal(got[c], oc.coset_lde(np.ascontiguousarray(coeffs[c]), n_out, G)), f"column {c}"
+    x = oc.splitmix(5 << 19, 4243).reshape(5, 1 << 19, 2)
+    f = ctx.ntt_batch(x)
+    for c in range(5):
+        assert np.array_equal(f[c], oc.ntt(np.ascontiguousarray(x[c])))
+    y = oc.splitmix(1 << 21, 4244)
+    assert ctx.merkle_commit_fe(y) == oc.merkle_commit_fe(y)
