@@ -532,3 +532,15 @@ def test_large_host_transfers_ragged_sizes(ctx):
         assert np.array_equal(f[c], oc.ntt(np.ascontiguousarray(x[c])))
     y = oc.splitmix(1 << 21, 4244)
     assert ctx.merkle_commit_fe(y) == oc.merkle_commit_fe(y)
+
+
+def test_reference_bench_case_2_12_u64_values(ctx):
+    """The reference's own bench input: 2^12 points with u64-sized values
+    (polynomial_benchmarks.rs:16-21,158), forward then inverse (ntt.rs:25-40)."""
+    n = 1 << 12
+    rng = np.random.default_rng(12)
+    x = np.zeros((n, 2), dtype=np.uint64)
+    x[:, 0] = rng.integers(0, 1 << 63, size=n, dtype=np.uint64) * 2 + rng.integers(0, 2, size=n, dtype=np.uint64)
+    f = ctx.ntt(x)
+    assert np.array_equal(f, oc.ntt(x))
+    assert np.array_equal(ctx.ntt(f, inverse=True), x)
