@@ -544,3 +544,106 @@ def test_reference_bench_case_2_12_u64_values(ctx):
     f = ctx.ntt(x)
     assert np.array_equal(f, oc.ntt(x))
     assert np.array_equal(ctx.ntt(f, inverse=True), x)
+
+
+def test_ntt_2_25_four_pass_plan(ctx):
+    """Above 2^24 the transform takes four global passes: bit-exact against the oracle."""
+    n = 1 << 25
+    x = oc.splitmix(n, 25)
+    f = ctx.ntt(x)
+    assert np.array_equal(f, oc.ntt(x))
+    assert np.array_equal(ctx.ntt(f, inverse=True), x)
+
+
+def _device_field_vector(n, seed):
+    """Canonical field elements generated on the device (hi < 2^62 < p >> 64)."""
+    import torch
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed)
+    d = torch.empty((n, 2), dtype=torch.int64, device="cuda")
+    d[:, 0] = torch.randint(-(1 << 63), (1 << 63) - 1, (n,), generator=g, device="cuda", dtype=torch.int64)
+    d[:, 1] = torch.randint(0, 1 << 62, (n,), generator=g, device="cuda", dtype=torch.int64)
+    return d
+
+
+def _sum_mod_p(d):
+    """Sum of the field elements of d (n, 2) modulo p, exact: 32-bit pieces summed in int64."""
+    total = 0
+    for col, shift in ((0, 0), (1, 64)):
+        v = d[:, col]
+        low = int((v & 0xFFFFFFFF).sum().item())
+        high = int(((v >> 32) & 0xFFFFFFFF).sum().item())
+        total += (low + (high << 32)) << shift
+    return total % P
+
+
+@pytest.mark.parametrize("log_n", [28, 30])
+def test_ntt_maximum_sizes_properties(ctx, log_n):
+    """Up to the largest size the reference admits (2^30, ntt.rs:15-16), where no
+    CPU check finishes: X[0] = sum x_j, X[n/2] = sum (-1)^j x_j, and the inverse
+    brings every element back."""
+    import torch
+    n = 1 << log_n
+    d = _device_field_vector(n, log_n)
+    want0 = _sum_mod_p(d)
+    even, odd = _sum_mod_p(d[0::2]), _sum_mod_p(d[1::2])
+    keep = d.clone()
+    ctx.ntt_dev(d, n, False)
+    ctx.synchronize()
+    got = d[[0, n // 2]].cpu().numpy().view(np.uint64)
+    assert oc.to_int(got[0]) == want0 == (even + odd) % P
+    assert oc.to_int(got[1]) == (even - odd) % P
+    ctx.ntt_dev(d, n, True)
+    ctx.synchronize()
+    assert torch.equal(d, keep)
+    del d, keep
+    torch.cuda.empty_cache()
+
+
+def test_fri_commit_2_26_spot_checks(ctx):
+    """A commit four times the headline size, checked by properties that need no
+    full CPU pass: sampled outputs of every fold against fri.rs:133-138 in Python
+    integers, and sampled openings of every layer against its root by
+    Merkle::verify (merkle.rs:96-132)."""
+    import torch
+    log_n = 26
+    n = 1 << log_n
+    d = _device_field_vector(n, 2600)
+    omega, offset = so.primitive_nth_root(n), G
+    stream, alphas = so.ProofStream(), []
+
+    def transcript(rnd, last, root):
+        stream.push(root.hex())
+        if last:
+            return None
+        alphas.append(so.fe_sample(stream.prover_fiat_shamir(32)))
+        return alphas[-1]
+
+    layers = ctx.fri_commit(d, offset, omega, 4, 17, transcript, n=n)
+    rounds = len(layers)
+    assert rounds == ctx.fri_num_rounds(n, 4, 17) == 20
+    rng = np.random.default_rng(26)
+    two_inv = so.fe_inverse(2)
+    om, of = omega, offset
+    for r in range(rounds):
+        m = layers.layer_len(r)
+        assert m == n >> r
+        idx = [0, m - 1] + [int(v) for v in rng.integers(0, m, size=2)]
+        vals = [oc.to_int(v) for v in layers.read(r, idx)]
+        root = layers.root(r)
+        for i, v in zip(idx[:3], vals[:3]):
+            assert so.merkle_verify(root, i, layers.open(r, i), so.bincode_field_element(v)), (r, i)
+        if r + 1 < rounds:
+            half = m // 2
+            js = [0, half - 1, int(rng.integers(0, half))]
+            a = [oc.to_int(v) for v in layers.read(r, js)]
+            b = [oc.to_int(v) for v in layers.read(r, [j + half for j in js])]
+            out = [oc.to_int(v) for v in layers.read(r + 1, js)]
+            for j, x, y, o in zip(js, a, b, out):
+                q = so.fe_div(alphas[r], so.fe_mul(of, so.fe_pow(om, j)))
+                want = so.fe_mul(two_inv, so.fe_add(so.fe_mul(so.fe_add(1, q), x), so.fe_mul(so.fe_sub(1, q), y)))
+                assert o == want, (r, j)
+            om, of = so.fe_mul(om, om), so.fe_mul(of, of)
+    layers.free()
+    del d
+    torch.cuda.empty_cache()
