@@ -313,7 +313,7 @@ def main():
     if rank == 0:
         extra.update(multi)
         if not args.no_cpu:
-            result["cpu_baseline"] = cpu_baseline(LOG_N, 2)
+            result["cpu_baseline"] = cpu_baseline(LOG_N, 6)      # about 12 s of CPU work
         else:
             result["cpu_baseline"] = None
         result["extra"] = extra
