@@ -234,11 +234,15 @@ def _all_gather(t: torch.Tensor, group) -> torch.Tensor:
     if world == 1:
         return t.unsqueeze(0)
     src = t.contiguous()
-    if src.is_cuda and dist.get_backend(group) != "nccl":
+    if dist.get_backend(group) == "nccl":
+        out = torch.empty((world,) + tuple(src.shape), dtype=src.dtype, device=src.device)
+        dist.all_gather_into_tensor(out, src, group=group)
+        return out
+    if src.is_cuda:
         src = src.cpu()
-    out = [torch.empty_like(src) for _ in range(world)]
-    dist.all_gather(out, src, group=group)
-    return torch.stack(out).to(t.device)
+    parts = [torch.empty_like(src) for _ in range(world)]
+    dist.all_gather(parts, src, group=group)
+    return torch.stack(parts).to(t.device)
 
 
 class ShardedFriCommit:
