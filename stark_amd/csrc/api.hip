@@ -225,7 +225,7 @@ static std::vector<tw5> powers_5(const HostField& F, fe x, size_t count)
 static std::vector<uint32_t> plan_radices(uint32_t log_n)
 {
     std::vector<uint32_t> r;
-    if (log_n <= (uint32_t)SMALL_MAX_LOG) return r;
+    if (log_n < (uint32_t)PASS_MIN_LOG) return r;
     uint32_t P = (log_n + 7) / 8;
     uint32_t base = log_n / P, rem = log_n % P;
     for (uint32_t q = 0; q < P; q++) r.push_back(base + (q < rem ? 1 : 0));
@@ -247,7 +247,7 @@ static int32_t get_ntt_tables(stark_ctx* ctx, uint32_t log_n, bool inverse, cons
     if (inverse) omega = F.inverse(omega);                    // ntt.rs:19
     fe n_inv = F.inverse(fe{(u64)1 << log_n, 0});             // ntt.rs:36
     t.scale_m = F.to_mont(n_inv);
-    if (log_n <= (uint32_t)SMALL_MAX_LOG) {
+    if (log_n < (uint32_t)PASS_MIN_LOG) {
         size_t half = log_n ? ((size_t)1 << (log_n - 1)) : 1;
         ST_TRY(upload(ctx, powers_m(F, omega, half), &t.small));
     } else {
@@ -325,8 +325,8 @@ static int32_t run_ntt(stark_ctx* ctx, const fe* src, size_t src_stride, size_t 
     ST_TRY(get_ntt_tables(ctx, log_n, inverse, &t));
     const size_t n = (size_t)1 << log_n;
     const PowTables* twist = nullptr;
-    if (twist_x) ST_TRY(get_pow_tables(ctx, *twist_x, n_src, log_n > (uint32_t)SMALL_MAX_LOG, &twist));
-    if (log_n <= (uint32_t)SMALL_MAX_LOG) {
+    if (twist_x) ST_TRY(get_pow_tables(ctx, *twist_x, n_src, log_n >= (uint32_t)PASS_MIN_LOG, &twist));
+    if (log_n < (uint32_t)PASS_MIN_LOG) {
         SmallArgs a{};
         a.tw = t->small;
         a.twist_hi = twist ? (const fe*)twist->hi : nullptr;

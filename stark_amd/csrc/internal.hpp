@@ -17,7 +17,8 @@ using starkh::digest;
 
 constexpr int TILE_ELEMS = 4096;      // elements per workgroup tile
 constexpr int TILE_THREADS = 256;
-constexpr int SMALL_MAX_LOG = 12;     // n <= 4096: one workgroup per transform
+constexpr int SMALL_MAX_LOG = 12;     // n <= 4096 fits one workgroup's LDS (ntt_small_kernel)
+constexpr int PASS_MIN_LOG = 12;      // from n = 4096 on the tiled multi-pass kernels are faster (two passes of 2^6)
 constexpr int MAX_PASSES = 4;
 
 // One global pass of the multi-pass NTT.  n = R_0 * R_1 * ... * R_{P-1}; pass q

@@ -422,7 +422,7 @@ static hipError_t launch_ra(const PassArgs& a, PassMode mode, bool twist, uint32
 
 hipError_t launch_ntt_pass(const PassArgs& a, PassMode mode, bool twist, uint32_t n_batch, hipStream_t s)
 {
-    if (a.log_n <= (uint32_t)SMALL_MAX_LOG || a.log_n > 30) return hipErrorInvalidValue;
+    if (a.log_n < (uint32_t)PASS_MIN_LOG || a.log_n > 30) return hipErrorInvalidValue;
     switch (a.r) {
     case 5: return launch_ra<1>(a, mode, twist, n_batch, s);
     case 6: return launch_ra<2>(a, mode, twist, n_batch, s);
