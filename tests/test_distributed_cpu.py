@@ -326,3 +326,45 @@ def test_shard_columns():
     from stark_amd.distributed import shard_columns
     assert shard_columns(64, 3, 8) == list(range(3, 64, 8))
     assert sorted(sum((shard_columns(5, r, 4) for r in range(4)), [])) == list(range(5))
+
+
+def test_prove_helpers_match_restatement():
+    """The wire strings and the index sampling the sharded prover uses are the
+    restatement's (fri.rs:54-87,146,188), including the short encodings."""
+    for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import stark_oracle as so
+    from stark_amd import distributed as D
+    vals = [0, 1, (1 << 32) - 1, 1 << 32, (1 << 64) + 5, 1 << 96, so.P - 1]
+    assert D.json_field_vec(vals) == so.json_field_vec(vals)
+    path = [bytes(range(32)), bytes([255] * 32), bytes(32)]
+    assert D.json_hash_path(path) == so.json_hash_path(path)
+    fri = so.Fri(so.GENERATOR, so.primitive_nth_root(256), 256, 4, 17)
+    for seed in (b"", b"seed", bytes(range(32))):
+        assert D.fri_sample_indices(seed, 128, 8, 6) == fri.sample_indices(seed, 128, 8, 6)
+    for n, e, t in ((1 << 24, 4, 17), (256, 4, 17), (512, 4, 2), (64, 8, 2)):
+        assert D.fri_num_rounds(n, e, t) == so.Fri(so.GENERATOR, so.primitive_nth_root(n), n, e, t).num_rounds()
+    assert D.fri_num_rounds(1 << 24, 4, 17) == 18 and D.fri_num_rounds(4, 4, 1) == 0
+
+
+def test_shard_layout_and_period():
+    from stark_amd import distributed as D
+    n, world, period = 64, 4, 16
+    full = torch.arange(2 * n, dtype=torch.int64).view(n, 2)
+    seen = []
+    for r in range(world):
+        sh = D.fri_shard_of(full, r, world, period)
+        pos = (sh[:, 0] // 2).tolist()
+        c = period // world
+        assert pos == [q * period + r * c + j for q in range(n // period) for j in range(c)]
+        # a position and its fold partner are in the same share
+        assert all(((p + n // 2) % n) in pos for p in pos)
+        seen += pos
+    assert sorted(seen) == list(range(n))
+    # the period is raised so that the last round is never a sharded one, and capped at n
+    assert D.fri_shard_period(1 << 24, 8, 4, 17) == 1 << 17
+    assert D.fri_shard_period(1 << 10, 4, 4, 2, 4) == 16
+    assert D.fri_shard_period(1 << 9, 2, 4, 2, None) == 1 << 9
+    with pytest.raises(ValueError, match="less than 1 round"):
+        D.fri_shard_period(4, 2, 4, 1)
