@@ -148,6 +148,11 @@ int32_t stark_merkle_commit_bytes(stark_ctx* ctx, const uint8_t* flat, const uin
  * sibling of the root's child; writes log2(n) digests of 32 bytes (for a
  * forest handle: log2(chunk_len), the siblings below the subtree root). */
 int32_t stark_merkle_open(stark_tree* tree, size_t index, uint8_t* path_out, size_t* depth_out);
+/* The same for `count` indices in one launch and one copy (a query round of
+ * Fri::query opens 3 x num_colinearity_tests leaves, fri.rs:182-204):
+ * paths_out receives count x depth digests, index by index. */
+int32_t stark_merkle_open_many(stark_tree* tree, const uint64_t* indices, size_t count, uint8_t* paths_out,
+                               size_t* depth_out);
 size_t stark_tree_num_leaves(const stark_tree* tree);
 /* All 2n-1 digests, leaf level first, each level followed by its parent level. */
 int32_t stark_tree_download(stark_tree* tree, uint8_t* out);
@@ -208,6 +213,16 @@ int32_t stark_fri_layer_read(stark_fri_layers* l, size_t layer, const uint64_t* 
 /* Merkle::open on a layer's retained tree (fri.rs:187,194,201). */
 int32_t stark_fri_layer_open(stark_fri_layers* l, size_t layer, size_t index, uint8_t* path_out,
                              size_t* depth_out);
+int32_t stark_fri_layer_open_many(stark_fri_layers* l, size_t layer, const uint64_t* indices, size_t count,
+                                  uint8_t* paths_out, size_t* depth_out);
+/* Everything one round of Fri::query reveals (fri.rs:155-209) in one round
+ * trip: for each c in c_indices (count of them, each < len(layer)/2) the
+ * values cw[layer][c], cw[layer][c + len/2], cw[layer+1][c] and their three
+ * authentication paths.  values_out: 3*count elements ordered [all a | all b |
+ * all c]; paths_out: [count a-paths | count b-paths] of *depth_out digests
+ * each, then count c-paths of *next_depth_out digests each. */
+int32_t stark_fri_layer_query(stark_fri_layers* l, size_t layer, const uint64_t* c_indices, size_t count,
+                              uint64_t* values_out, uint8_t* paths_out, size_t* depth_out, size_t* next_depth_out);
 void stark_fri_layers_free(stark_fri_layers* l);
 
 #ifdef __cplusplus

@@ -47,6 +47,7 @@ SIGNATURES = {
     "stark_merkle_root_of_digests_dev": (i32, [C.c_void_p, C.c_void_p, sz, u8p, voidpp]),
     "stark_merkle_commit_bytes": (i32, [C.c_void_p, C.c_void_p, C.c_void_p, sz, u8p, voidpp]),
     "stark_merkle_open": (i32, [C.c_void_p, sz, u8p, szp]),
+    "stark_merkle_open_many": (i32, [C.c_void_p, C.c_void_p, sz, C.c_void_p, szp]),
     "stark_tree_num_leaves": (sz, [C.c_void_p]),
     "stark_tree_download": (i32, [C.c_void_p, C.c_void_p]),
     "stark_tree_free": (None, [C.c_void_p]),
@@ -63,6 +64,8 @@ SIGNATURES = {
     "stark_fri_layer_download": (i32, [C.c_void_p, sz, C.c_void_p]),
     "stark_fri_layer_read": (i32, [C.c_void_p, sz, u64p, sz, C.c_void_p]),
     "stark_fri_layer_open": (i32, [C.c_void_p, sz, sz, u8p, szp]),
+    "stark_fri_layer_open_many": (i32, [C.c_void_p, sz, C.c_void_p, sz, C.c_void_p, szp]),
+    "stark_fri_layer_query": (i32, [C.c_void_p, sz, C.c_void_p, sz, C.c_void_p, C.c_void_p, szp, szp]),
     "stark_fri_layers_free": (None, [C.c_void_p]),
 }
 

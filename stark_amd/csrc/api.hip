@@ -141,9 +141,21 @@ static int log2_exact(size_t n)
     return l;
 }
 
+// Device scratch is recycled through a small cache keyed by block size.  Requests below 1 MiB are
+// rounded up to a power of two (at least 256 B) so that the many short-lived buffers of a query
+// phase (index lists, paths, a few elements) hit the cache whatever their exact length: a
+// hipMalloc/hipFree pair costs far more than the kernels they serve, and hipFree drains the device.
+static size_t pool_bucket(size_t bytes)
+{
+    if (bytes >= ((size_t)1 << 20)) return bytes;
+    size_t b = 256;
+    while (b < bytes) b <<= 1;
+    return b;
+}
+
 static int32_t pool_alloc(stark_ctx* ctx, size_t bytes, void** out)
 {
-    if (bytes == 0) bytes = 16;
+    bytes = pool_bucket(bytes);
     auto it = ctx->pool.find(bytes);
     if (it != ctx->pool.end()) {
         *out = it->second;
@@ -164,9 +176,12 @@ static int32_t pool_alloc(stark_ctx* ctx, size_t bytes, void** out)
 static void pool_free(stark_ctx* ctx, void* p, size_t bytes)
 {
     if (!p) return;
-    if (bytes == 0) bytes = 16;
-    // keep at most a handful of cached blocks
-    if (ctx->pool.size() >= 16) {
+    bytes = pool_bucket(bytes);
+    // keep at most a handful of large blocks (they can be gigabytes) and a few hundred small ones
+    size_t large = 0;
+    if (bytes >= ((size_t)1 << 20))
+        for (auto& kv : ctx->pool) large += kv.first >= ((size_t)1 << 20);
+    if (large >= 16 || ctx->pool.size() >= 512) {
         (void)hipFree(p);
         return;
     }
@@ -666,6 +681,28 @@ static int32_t tree_open(stark_ctx* ctx, const digest* tree, size_t n, size_t in
     return STARK_OK;
 }
 
+static int32_t tree_open_many(stark_ctx* ctx, const digest* tree, size_t n, int max_levels, const uint64_t* indices,
+                              size_t count, uint8_t* paths_out, size_t* depth_out)
+{
+    int depth = log2_exact(n);
+    if (depth < 0) return fail(STARK_ENOTPOW2, "length must be power of two");
+    if (depth > max_levels) depth = max_levels;
+    if (depth_out) *depth_out = (size_t)depth;
+    if (count > 0xFFFFFFFFull) return fail(STARK_ELENGTH, "too many openings in one call");
+    for (size_t i = 0; i < count; i++)
+        if (indices[i] >= n) return fail(STARK_EINDEX, "cannot open invalid index");
+    if (count == 0 || depth == 0) return STARK_OK;
+    DevBuf idx(ctx), paths(ctx);
+    const size_t path_bytes = count * (size_t)depth * sizeof(digest);
+    ST_TRY(idx.alloc(count * sizeof(uint64_t)));
+    ST_TRY(paths.alloc(path_bytes));
+    HIP_TRY(hipMemcpyAsync(idx.p, indices, count * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(launch_merkle_open_many(tree, n, (const uint64_t*)idx.p, count, (uint32_t)depth, (digest*)paths.p, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(paths_out, paths.p, path_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return STARK_OK;
+}
+
 }  // namespace
 
 // ===========================================================================
@@ -981,6 +1018,14 @@ extern "C" int32_t stark_merkle_open(stark_tree* tree, size_t index, uint8_t* pa
     CtxGuard guard_(tree ? tree->ctx : nullptr);
     if (!tree || !path_out) return fail(STARK_EARG, "null argument");
     return tree_open(tree->ctx, tree->d, tree->n, index, path_out, depth_out, (int)tree->levels);
+}
+
+extern "C" int32_t stark_merkle_open_many(stark_tree* tree, const uint64_t* indices, size_t count, uint8_t* paths_out,
+                                          size_t* depth_out)
+{
+    CtxGuard guard_(tree ? tree->ctx : nullptr);
+    if (!tree || (count && (!indices || !paths_out))) return fail(STARK_EARG, "null argument");
+    return tree_open_many(tree->ctx, tree->d, tree->n, (int)tree->levels, indices, count, paths_out, depth_out);
 }
 
 extern "C" size_t stark_tree_num_leaves(const stark_tree* tree) { return tree ? tree->n : 0; }
@@ -1301,6 +1346,56 @@ extern "C" int32_t stark_fri_layer_open(stark_fri_layers* l, size_t layer, size_
     CtxGuard guard_(l ? l->ctx : nullptr);
     if (!l || !path_out || layer >= l->len.size()) return fail(STARK_EARG, "bad layer");
     return tree_open(l->ctx, l->tree[layer], l->len[layer], index, path_out, depth_out);
+}
+
+extern "C" int32_t stark_fri_layer_open_many(stark_fri_layers* l, size_t layer, const uint64_t* indices, size_t count,
+                                             uint8_t* paths_out, size_t* depth_out)
+{
+    CtxGuard guard_(l ? l->ctx : nullptr);
+    if (!l || layer >= l->len.size() || (count && (!indices || !paths_out))) return fail(STARK_EARG, "bad layer");
+    return tree_open_many(l->ctx, l->tree[layer], l->len[layer], 64, indices, count, paths_out, depth_out);
+}
+
+extern "C" int32_t stark_fri_layer_query(stark_fri_layers* l, size_t layer, const uint64_t* c_indices, size_t count,
+                                         uint64_t* values_out, uint8_t* paths_out, size_t* depth_out,
+                                         size_t* next_depth_out)
+{
+    CtxGuard guard_(l ? l->ctx : nullptr);
+    if (!l || layer + 1 >= l->len.size() || !c_indices || !values_out || !paths_out) return fail(STARK_EARG, "bad layer");
+    if (count == 0) return STARK_OK;
+    if (count > 0x7FFFFFFFull / 3) return fail(STARK_ELENGTH, "too many openings in one call");
+    const size_t n = l->len[layer], half = n / 2, n_next = l->len[layer + 1];
+    const int depth = log2_exact(n), depth_next = log2_exact(n_next);
+    for (size_t i = 0; i < count; i++)
+        if (c_indices[i] >= half || c_indices[i] >= n_next) return fail(STARK_EINDEX, "cannot open invalid index");
+    if (depth_out) *depth_out = (size_t)depth;
+    if (next_depth_out) *next_depth_out = (size_t)depth_next;
+    stark_ctx* ctx = l->ctx;
+    // one staging block: [3*count indices | 3*count values | paths], one copy in, one copy out, one sync
+    const size_t idx_bytes = 3 * count * sizeof(uint64_t), val_bytes = 3 * count * sizeof(fe);
+    const size_t path_digests = count * (2 * (size_t)depth + (size_t)depth_next);
+    std::vector<uint64_t> idx(3 * count);
+    for (size_t i = 0; i < count; i++) {
+        idx[i] = c_indices[i];                   // a
+        idx[count + i] = c_indices[i] + half;    // b (fri.rs:160-163)
+        idx[2 * count + i] = c_indices[i];       // c, in the next layer
+    }
+    DevBuf stage(ctx);
+    ST_TRY(stage.alloc(idx_bytes + val_bytes + path_digests * sizeof(digest) + 64));
+    uint64_t* d_idx = (uint64_t*)stage.p;
+    fe* d_val = (fe*)((uint8_t*)stage.p + idx_bytes);
+    digest* d_path = (digest*)((uint8_t*)stage.p + idx_bytes + val_bytes);
+    HIP_TRY(hipMemcpyAsync(d_idx, idx.data(), idx_bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(launch_gather_fe(l->cw[layer], d_idx, d_val, 2 * count, ctx->stream));
+    HIP_TRY(launch_gather_fe(l->cw[layer + 1], d_idx + 2 * count, d_val + 2 * count, count, ctx->stream));
+    HIP_TRY(launch_merkle_open_many(l->tree[layer], n, d_idx, 2 * count, (uint32_t)depth, d_path, ctx->stream));
+    HIP_TRY(launch_merkle_open_many(l->tree[layer + 1], n_next, d_idx + 2 * count, count, (uint32_t)depth_next,
+                                    d_path + 2 * count * (size_t)depth, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(values_out, d_val, val_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (path_digests)
+        HIP_TRY(hipMemcpyAsync(paths_out, d_path, path_digests * sizeof(digest), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return STARK_OK;
 }
 
 extern "C" void stark_fri_layers_free(stark_fri_layers* l)

@@ -436,6 +436,26 @@ hipError_t launch_merkle_open(const digest* tree, size_t n, size_t index, digest
     return hipGetLastError();
 }
 
+// Many openings of one tree at once: block b serves idx[b], thread k fetches the sibling on level k.
+__global__ void merkle_open_many_kernel(const digest* __restrict__ tree, size_t n, const uint64_t* __restrict__ idx,
+                                        uint32_t levels, digest* __restrict__ paths)
+{
+    const uint32_t k = threadIdx.x;
+    if (k >= levels) return;
+    const size_t index = idx[blockIdx.x];
+    size_t m = n, off = 0;
+    for (uint32_t l = 0; l < k; l++) { off += m; m >>= 1; }
+    paths[(size_t)blockIdx.x * levels + k] = tree[off + ((index >> k) ^ 1)];
+}
+
+hipError_t launch_merkle_open_many(const digest* tree, size_t n, const uint64_t* idx_dev, size_t count, uint32_t levels,
+                                   digest* paths_out, hipStream_t s)
+{
+    if (count == 0 || levels == 0) return hipSuccess;
+    hipLaunchKernelGGL(merkle_open_many_kernel, dim3((uint32_t)count), dim3(64), 0, s, tree, n, idx_dev, levels, paths_out);
+    return hipGetLastError();
+}
+
 __global__ void gather_fe_kernel(const fe* __restrict__ src, const uint64_t* __restrict__ idx, fe* __restrict__ out,
                                  size_t count)
 {

@@ -111,6 +111,10 @@ hipError_t launch_fri_fold_commit(const FoldArgs& a, hipStream_t s, digest* root
 hipError_t launch_merkle_open(const digest* tree, size_t n, size_t index, digest* path_out, hipStream_t s,
                               uint32_t max_levels = 64);
 
+// count openings of one tree: paths_out[b*levels + k] = sibling of idx[b] on level k (levels <= 64)
+hipError_t launch_merkle_open_many(const digest* tree, size_t n, const uint64_t* idx_dev, size_t count, uint32_t levels,
+                                   digest* paths_out, hipStream_t s);
+
 hipError_t launch_gather_fe(const fe* src, const uint64_t* idx, fe* out, size_t count, hipStream_t s);
 
 }  // namespace starkk

@@ -61,6 +61,17 @@ class Tree:
         raw = bytes(buf)
         return [raw[32 * i:32 * i + 32] for i in range(depth.value)]
 
+    def open_many(self, indices: Sequence[int]) -> List[List[bytes]]:
+        """open() for several indices in one launch."""
+        idx = np.asarray(list(indices), dtype=np.uint64)
+        out = np.empty((max(len(idx), 1), 64, 32), dtype=np.uint8)
+        depth = C.c_size_t(0)
+        self.ctx._chk(self.ctx.lib.stark_merkle_open_many(self.h, idx.ctypes.data, len(idx), out.ctypes.data,
+                                                          C.byref(depth)))
+        flat = out.reshape(-1, 32)
+        d = depth.value
+        return [[flat[i * d + k].tobytes() for k in range(d)] for i in range(len(idx))]
+
     def download(self) -> np.ndarray:
         n = self.num_leaves
         out = np.empty((2 * n - 1, 32), dtype=np.uint8)
@@ -114,6 +125,33 @@ class FriLayers:
         self.ctx._chk(self.ctx.lib.stark_fri_layer_open(self.h, i, index, buf, C.byref(depth)))
         raw = bytes(buf)
         return [raw[32 * k:32 * k + 32] for k in range(depth.value)]
+
+    def open_many(self, i: int, indices: Sequence[int]) -> List[List[bytes]]:
+        """open() for several indices of layer i in one launch."""
+        idx = np.asarray(list(indices), dtype=np.uint64)
+        out = np.empty((max(len(idx), 1), 64, 32), dtype=np.uint8)
+        depth = C.c_size_t(0)
+        self.ctx._chk(self.ctx.lib.stark_fri_layer_open_many(self.h, i, idx.ctypes.data, len(idx), out.ctypes.data,
+                                                             C.byref(depth)))
+        flat = out.reshape(-1, 32)
+        d = depth.value
+        return [[flat[j * d + k].tobytes() for k in range(d)] for j in range(len(idx))]
+
+    def query(self, i: int, c_indices: Sequence[int]):
+        """One round of Fri::query on layers i and i+1: (values (3, count, 2) for a, b, c; paths_a, paths_b,
+        paths_c as lists of digest lists), one round trip."""
+        idx = np.asarray(list(c_indices), dtype=np.uint64)
+        t = len(idx)
+        vals = np.empty((3, max(t, 1), 2), dtype=np.uint64)
+        paths = np.empty((max(t, 1) * 3 * 64, 32), dtype=np.uint8)
+        d, dn = C.c_size_t(0), C.c_size_t(0)
+        self.ctx._chk(self.ctx.lib.stark_fri_layer_query(self.h, i, idx.ctypes.data, t, vals.ctypes.data,
+                                                         paths.ctypes.data, C.byref(d), C.byref(dn)))
+        d, dn = d.value, dn.value
+
+        def cut(base, depth):
+            return [[paths[base + j * depth + k].tobytes() for k in range(depth)] for j in range(t)]
+        return vals[:, :t], cut(0, d), cut(t * d, d), cut(2 * t * d, dn)
 
     def free(self):
         if self.h:

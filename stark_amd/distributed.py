@@ -363,6 +363,15 @@ def fri_sample_indices(seed: bytes, size: int, reduced_size: int, number: int) -
     return indices
 
 
+def _open_many(handle, indices: Sequence[int]) -> List[List[bytes]]:
+    """Paths of several indices from a retained tree or forest: one launch when the handle offers it."""
+    if not indices:
+        return []
+    if hasattr(handle, "open_many"):
+        return handle.open_many(list(indices))
+    return [handle.open(i) for i in indices]
+
+
 def _sharded_openings(engine, commit: ShardedFriCommit, layer: int, positions: Sequence[int], rank: int, world: int,
                       group):
     """Values and authentication paths of `positions` in sharded layer `layer`, on every rank: the
@@ -375,20 +384,21 @@ def _sharded_openings(engine, commit: ShardedFriCommit, layer: int, positions: S
     buf = torch.zeros((len(positions), slot), dtype=torch.uint8)
     mine = [(s, (i // period) * c + i % c) for s, i in enumerate(positions) if (i % period) // c == rank]
     vals = engine.read_elements(commit.shares[layer], [l for _, l in mine])
-    for (s, l), v in zip(mine, vals):
-        raw = v.to_bytes(16, "little") + b"".join(commit.forests[layer].open(l))
+    subs = _open_many(commit.forests[layer], [l for _, l in mine])
+    for (s, _), v, sub in zip(mine, vals, subs):
+        raw = v.to_bytes(16, "little") + b"".join(sub)
         buf[s] = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
     if world > 1:
         dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else buf.device
         t = buf.to(torch.int32).to(dev)                  # byte sums of one owner and zeros: exact in any integer type
         dist.all_reduce(t, group=group)
         buf = t.cpu().to(torch.uint8)
+    uppers = _open_many(commit.tops[layer], [i // c for i in positions])
     out = []
-    for s, i in enumerate(positions):
+    for s in range(len(positions)):
         raw = bytes(buf[s].tolist())
         value = int.from_bytes(raw[:16], "little")
-        path = [raw[16 + 32 * j:48 + 32 * j] for j in range(sub_levels)] + commit.tops[layer].open(i // c)
-        out.append((value, path))
+        out.append((value, [raw[16 + 32 * j:48 + 32 * j] for j in range(sub_levels)] + uppers[s]))
     return out
 
 
@@ -421,8 +431,9 @@ def fri_prove_sharded(engine, local: torch.Tensor, n: int, offset: int, omega: i
             if layer < k_sh:
                 return _sharded_openings(engine, commit, layer, positions, rank, world, group)
             vals = tail.read(layer - k_sh, positions)
-            return [(int(lo) | (int(hi) << 64), tail.open(layer - k_sh, i))
-                    for (lo, hi), i in zip(vals.tolist(), positions)]
+            paths = tail.open_many(layer - k_sh, positions) if hasattr(tail, "open_many") else \
+                [tail.open(layer - k_sh, i) for i in positions]
+            return [(int(lo) | (int(hi) << 64), p) for (lo, hi), p in zip(vals.tolist(), paths)]
 
         indices = list(top)
         for i in range(rounds - 1):                                     # fri.rs:228-242

@@ -246,6 +246,17 @@ int sh_fri_commit_resident(const void* cw_dev, size_t n, const uint64_t* offset,
         std::unique_ptr<LayersHandle> h = f.commit_resident((const uint64_t*)cw_dev, *static_cast<ProofStream*>(ps));
         return (int)stark_fri_layers_count(h->l);)
 }
+// Fri::prove (fri.rs:212-254) of a codeword resident on the device: commit, then the query phase
+// answered from the retained layers; returns the number of indices written (2 * ncol).
+int sh_fri_prove_resident(const void* cw_dev, size_t n, const uint64_t* offset, const uint64_t* omega, size_t expansion,
+                          size_t ncol, void* ps, uint64_t* indices_out)
+{
+    GUARD(
+        Fri f = make_fri(offset, omega, n, expansion, ncol);
+        std::vector<size_t> idx = f.prove_resident((const uint64_t*)cw_dev, *static_cast<ProofStream*>(ps));
+        for (size_t i = 0; i < idx.size(); i++) indices_out[i] = idx[i];
+        return (int)idx.size();)
+}
 // the process-wide device context the mirror runs on (for callers that stage device buffers)
 void* sh_context()
 {

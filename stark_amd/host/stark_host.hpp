@@ -292,17 +292,24 @@ typedef std::array<uint8_t, 32> HashOutput;
 
 inline std::string json_hash_path(const std::vector<HashOutput>& path)          // fri.rs:188
 {
-    std::string s = "[";
+    // a proof carries hundreds of thousands of these bytes: decimal digits by hand, one allocation
+    std::string s;
+    s.reserve(path.size() * (32 * 4 + 2) + 2);
+    s += '[';
     for (size_t i = 0; i < path.size(); i++) {
-        if (i) s += ",";
-        s += "[";
+        if (i) s += ',';
+        s += '[';
         for (int b = 0; b < 32; b++) {
-            if (b) s += ",";
-            s += std::to_string((int)path[i][b]);
+            if (b) s += ',';
+            const unsigned v = path[i][b];
+            if (v >= 100) s += (char)('0' + v / 100);
+            if (v >= 10) s += (char)('0' + v / 10 % 10);
+            s += (char)('0' + v % 10);
         }
-        s += "]";
+        s += ']';
     }
-    return s + "]";
+    s += ']';
+    return s;
 }
 inline std::vector<HashOutput> json_hash_path_parse(const std::string& str)
 {
@@ -750,6 +757,16 @@ struct Merkle {
         check(stark_merkle_commit_bytes(context(), flat.data(), offs.data(), data_array.size(), root.data(), &th.t));
         return open_tree(th.t, index);
     }
+    static std::vector<std::vector<HashOutput>> open_tree_many(stark_tree* t, const std::vector<uint64_t>& indices)
+    {
+        std::vector<uint8_t> buf(indices.size() * 64 * 32 + 32);
+        size_t depth = 0;
+        check(stark_merkle_open_many(t, indices.data(), indices.size(), buf.data(), &depth));
+        std::vector<std::vector<HashOutput>> out(indices.size(), std::vector<HashOutput>(depth));
+        for (size_t i = 0; i < indices.size(); i++)
+            for (size_t k = 0; k < depth; k++) std::memcpy(out[i][k].data(), buf.data() + 32 * (i * depth + k), 32);
+        return out;
+    }
     static std::vector<HashOutput> open_tree(stark_tree* t, size_t index)
     {
         uint8_t buf[64 * 32];
@@ -904,19 +921,23 @@ struct Fri {
         std::vector<size_t> a_indices = c_indices, b_indices;
         for (size_t idx : c_indices) b_indices.push_back(idx + cur_len / 2);
         size_t t = num_colinearity_tests;
-        std::vector<uint64_t> ia(a_indices.begin(), a_indices.begin() + t), ib(b_indices.begin(), b_indices.begin() + t),
-            ic(c_indices.begin(), c_indices.begin() + t);
-        std::vector<uint64_t> va(2 * t), vb(2 * t), vc(2 * t);
-        check(stark_fri_layer_read(l, layer, ia.data(), t, va.data()));
-        check(stark_fri_layer_read(l, layer, ib.data(), t, vb.data()));
-        check(stark_fri_layer_read(l, layer + 1, ic.data(), t, vc.data()));
-        std::vector<FieldElement> ea = unpack(va), eb = unpack(vb), ec = unpack(vc);
-        for (size_t s = 0; s < t; s++)
-            ps.push(wire::json_string_triple(ea[s].to_string(), eb[s].to_string(), ec[s].to_string()));
-        for (size_t s = 0; s < t; s++) {
-            ps.push(wire::json_hash_path(open_layer(l, layer, a_indices[s])));
-            ps.push(wire::json_hash_path(open_layer(l, layer, b_indices[s])));
-            ps.push(wire::json_hash_path(open_layer(l, layer + 1, c_indices[s])));
+        // the 3t points and 3t paths of the round in one round trip
+        std::vector<uint64_t> ic(c_indices.begin(), c_indices.begin() + t), vals(6 * t);
+        std::vector<uint8_t> raw(3 * t * 64 * 32 + 32);
+        size_t depth = 0, depth_next = 0;
+        check(stark_fri_layer_query(l, layer, ic.data(), t, vals.data(), raw.data(), &depth, &depth_next));
+        std::vector<FieldElement> e = unpack(vals);
+        for (size_t s = 0; s < t; s++)                                                       // :166-179
+            ps.push(wire::json_string_triple(e[s].to_string(), e[t + s].to_string(), e[2 * t + s].to_string()));
+        auto path_at = [&](size_t base, size_t d, size_t s) {
+            std::vector<HashOutput> p(d);
+            for (size_t k = 0; k < d; k++) std::memcpy(p[k].data(), raw.data() + 32 * (base + s * d + k), 32);
+            return p;
+        };
+        for (size_t s = 0; s < t; s++) {                                                     // :182-204
+            ps.push(wire::json_hash_path(path_at(0, depth, s)));
+            ps.push(wire::json_hash_path(path_at(t * depth, depth, s)));
+            ps.push(wire::json_hash_path(path_at(2 * t * depth, depth_next, s)));
         }
         a_indices.insert(a_indices.end(), b_indices.begin(), b_indices.end());
         return a_indices;
@@ -964,6 +985,11 @@ struct Fri {
         for (size_t i = 0; i + 1 < layers; i++) {
             size_t half = stark_fri_layer_len(h->l, i) / 2;
             for (size_t& idx : indices) idx %= half;
+            // query() returns a and b for EVERY index it was given, so the reference's list doubles
+            // each round (fri.rs:160-163,207-208) although only its first num_colinearity_tests
+            // entries are ever read (:166-203); keeping just those gives the same stream without
+            // a list of t * 2^rounds entries
+            if (indices.size() > num_colinearity_tests) indices.resize(num_colinearity_tests);
             indices = query_device(h->l, i, indices, ps);
         }
         std::vector<size_t> out = top;
@@ -1058,6 +1084,21 @@ private:
         std::vector<uint64_t> buf(2 * stark_fri_layer_len(l, layer));
         check(stark_fri_layer_download(l, layer, buf.data()));
         return unpack(buf);
+    }
+    static std::vector<std::vector<HashOutput>> paths_from(const std::vector<uint8_t>& buf, size_t count, size_t depth)
+    {
+        std::vector<std::vector<HashOutput>> out(count, std::vector<HashOutput>(depth));
+        for (size_t i = 0; i < count; i++)
+            for (size_t k = 0; k < depth; k++) std::memcpy(out[i][k].data(), buf.data() + 32 * (i * depth + k), 32);
+        return out;
+    }
+    static std::vector<std::vector<HashOutput>> open_layer_many(stark_fri_layers* l, size_t layer,
+                                                                const std::vector<uint64_t>& indices)
+    {
+        std::vector<uint8_t> buf(indices.size() * 64 * 32 + 32);
+        size_t depth = 0;
+        check(stark_fri_layer_open_many(l, layer, indices.data(), indices.size(), buf.data(), &depth));
+        return paths_from(buf, indices.size(), depth);
     }
     static std::vector<HashOutput> open_layer(stark_fri_layers* l, size_t layer, size_t index)
     {

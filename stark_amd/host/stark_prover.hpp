@@ -411,6 +411,11 @@ struct Stark {
             return FieldElement{((u128)v[1] << 64) | v[0]};
         }
         std::vector<HashOutput> open(size_t c, size_t i) const { return Merkle::open_tree(trees[c]->t, i); }
+        // the paths of many indices of one column in one launch
+        std::vector<std::vector<HashOutput>> open_many(size_t c, const std::vector<uint64_t>& idx) const
+        {
+            return Merkle::open_tree_many(trees[c]->t, idx);
+        }
     };
     Codewords commit_polynomials(const std::vector<Polynomial>& polys, bool with_trees) const
     {
@@ -513,14 +518,18 @@ struct Stark {
         std::vector<size_t> duplicated = indices;                                           // :415-419
         for (size_t i : indices) duplicated.push_back((i + expansion_factor) % fri.domain_length);
         std::sort(duplicated.begin(), duplicated.end());
-        for (size_t s = 0; s < num_registers; s++)                                          // :429-443
-            for (size_t i : duplicated) {
-                ps.push(wire::json_field_element(bq.at(s, i)));
-                ps.push(wire::json_hash_path(bq.open(s, i)));
+        const std::vector<uint64_t> dup64(duplicated.begin(), duplicated.end()), idx64(indices.begin(), indices.end());
+        for (size_t s = 0; s < num_registers; s++) {                                        // :429-443
+            const std::vector<std::vector<HashOutput>> paths = bq.open_many(s, dup64);
+            for (size_t k = 0; k < duplicated.size(); k++) {
+                ps.push(wire::json_field_element(bq.at(s, duplicated[k])));
+                ps.push(wire::json_hash_path(paths[k]));
             }
-        for (size_t i : indices) {                                                          // :449-464
-            ps.push(wire::json_field_element(rz.at(0, i)));
-            ps.push(wire::json_hash_path(rz.open(0, i)));
+        }
+        const std::vector<std::vector<HashOutput>> rz_paths = rz.open_many(0, idx64);
+        for (size_t k = 0; k < indices.size(); k++) {                                       // :449-464
+            ps.push(wire::json_field_element(rz.at(0, indices[k])));
+            ps.push(wire::json_hash_path(rz_paths[k]));
         }
         return ps.serialize();                                                              // :470
     }

@@ -135,6 +135,14 @@ def fri_commit_resident(dev_ptr, n, offset, omega, expansion, ncol, stream):
                                           C.c_size_t(ncol), stream.h))
 
 
+def fri_prove_resident(dev_ptr, n, offset, omega, expansion, ncol, stream):
+    """Fri::prove (fri.rs:212-254) of a codeword resident on the device; returns the top-level indices."""
+    out = (C.c_uint64 * (2 * ncol))()
+    k = chk(lib.sh_fri_prove_resident(_vp(dev_ptr), C.c_size_t(n), fe(offset), fe(omega), C.c_size_t(expansion),
+                                      C.c_size_t(ncol), stream.h, out))
+    return [int(out[i]) for i in range(k)]
+
+
 def fri_verify(offset, omega, n, expansion, ncol, stream, max_points=4096):
     idx = np.zeros(max_points, dtype=np.uint64)
     vals = np.zeros((max_points, 2), dtype=np.uint64)

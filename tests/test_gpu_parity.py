@@ -647,3 +647,53 @@ def test_fri_commit_2_26_spot_checks(ctx):
     layers.free()
     del d
     torch.cuda.empty_cache()
+
+
+def test_open_many_equals_single_opens(ctx):
+    """Batched openings (trees and FRI layers) are the single openings, index by index."""
+    from stark_amd import StarkError
+    n = 1 << 11
+    x = oc.splitmix(n, 1234)
+    root, tree = ctx.merkle_commit_fe(x, keep_tree=True)
+    idx = [0, 1, n - 1, 777, 777, 1024]
+    many = tree.open_many(idx)
+    ref_tree = oc.merkle_tree_fe(x)
+    for i, p in zip(idx, many):
+        assert p == tree.open(i) == oc.merkle_open(ref_tree, i)
+    assert tree.open_many([]) == []
+    with pytest.raises(StarkError, match="cannot open invalid index"):
+        tree.open_many([0, n])
+    tree.free()
+    layers = ctx.fri_commit(x, G, so.primitive_nth_root(n), 4, 3, lambda r, last, root: None if last else 5 + r)
+    for layer in (0, len(layers) - 1):
+        m = layers.layer_len(layer)
+        idx = [0, m - 1, m // 3]
+        assert layers.open_many(layer, idx) == [layers.open(layer, i) for i in idx]
+    layers.free()
+    one = ctx.merkle_commit_fe(x[:1], keep_tree=True)[1]
+    assert one.open_many([0]) == [[]]
+    one.free()
+
+
+def test_fri_layer_query_equals_reads_and_opens(ctx):
+    """One round of Fri::query in one round trip gives the values and paths of
+    the separate reads and openings (fri.rs:155-209)."""
+    from stark_amd import StarkError
+    n = 1 << 12
+    x = oc.splitmix(n, 4321)
+    layers = ctx.fri_commit(x, G, so.primitive_nth_root(n), 4, 3, lambda r, last, root: None if last else 11 + r)
+    for layer in (0, 3, len(layers) - 2):
+        m = layers.layer_len(layer)
+        cs = [0, m // 2 - 1, (m // 5) | 1, 7 % (m // 2)]
+        vals, pa, pb, pc = layers.query(layer, cs)
+        assert np.array_equal(vals[0], layers.read(layer, cs))
+        assert np.array_equal(vals[1], layers.read(layer, [c + m // 2 for c in cs]))
+        assert np.array_equal(vals[2], layers.read(layer + 1, cs))
+        assert pa == [layers.open(layer, c) for c in cs]
+        assert pb == [layers.open(layer, c + m // 2) for c in cs]
+        assert pc == [layers.open(layer + 1, c) for c in cs]
+    with pytest.raises(StarkError, match="cannot open invalid index"):
+        layers.query(0, [n // 2])
+    with pytest.raises(StarkError, match="bad layer"):
+        layers.query(len(layers) - 1, [0])
+    layers.free()
