@@ -292,23 +292,39 @@ typedef std::array<uint8_t, 32> HashOutput;
 
 inline std::string json_hash_path(const std::vector<HashOutput>& path)          // fri.rs:188
 {
-    // a proof carries hundreds of thousands of these bytes: decimal digits by hand, one allocation
-    std::string s;
-    s.reserve(path.size() * (32 * 4 + 2) + 2);
-    s += '[';
-    for (size_t i = 0; i < path.size(); i++) {
-        if (i) s += ',';
-        s += '[';
-        for (int b = 0; b < 32; b++) {
-            if (b) s += ',';
-            const unsigned v = path[i][b];
-            if (v >= 100) s += (char)('0' + v / 100);
-            if (v >= 10) s += (char)('0' + v / 10 % 10);
-            s += (char)('0' + v % 10);
+    // a proof carries hundreds of thousands of these bytes: a table of "0," .. "255," and one buffer
+    struct Table {
+        char text[256][4];
+        uint8_t len[256];
+        Table()
+        {
+            for (unsigned v = 0; v < 256; v++) {
+                unsigned k = 0;
+                if (v >= 100) text[v][k++] = (char)('0' + v / 100);
+                if (v >= 10) text[v][k++] = (char)('0' + v / 10 % 10);
+                text[v][k++] = (char)('0' + v % 10);
+                text[v][k++] = ',';
+                len[v] = (uint8_t)k;
+            }
         }
-        s += ']';
+    };
+    static const Table T;
+    std::string s(path.size() * (32 * 4 + 2) + 2, '\0');
+    char* p = &s[0];
+    *p++ = '[';
+    for (size_t i = 0; i < path.size(); i++) {
+        *p++ = '[';
+        for (int b = 0; b < 32; b++) {
+            const unsigned v = path[i][b];
+            std::memcpy(p, T.text[v], 4);
+            p += T.len[v];
+        }
+        p[-1] = ']';                      // over the last comma
+        *p++ = ',';
     }
-    s += ']';
+    if (!path.empty()) p--;               // drop the comma after the last digest
+    *p++ = ']';
+    s.resize((size_t)(p - &s[0]));
     return s;
 }
 inline std::vector<HashOutput> json_hash_path_parse(const std::string& str)
