@@ -81,6 +81,7 @@ struct stark_ctx {
     size_t scratch_elems = 0;
     std::multimap<size_t, void*> pool;                 // cached device blocks by size
     void* pinned = nullptr;                            // small pinned staging buffer (4 KiB)
+    void* pin_io = nullptr;                            // 2 x 64 KiB host-mapped: small transforms run on it in place
     std::recursive_mutex mu;
     // Lanes for large transfers between pageable host memory and the device: each has a stream
     // of its own and two pinned chunks (created on first use).
@@ -424,6 +425,10 @@ static bool is_canonical(fe x) { return !ge_p(x.lo, x.hi); }
 // several lanes do the same staging side by side, each on its own thread and
 // stream, which brings the rate close to what the link gives for pinned memory.
 // ---------------------------------------------------------------------------
+// A host-pointer transform whose data fits this many bytes (up to 4096 elements) runs on host-mapped
+// pinned memory directly: the kernels read and write it over the link, so a call is launch +
+// synchronisation instead of copy + launch + copy.
+constexpr size_t SMALL_IO_BYTES = (size_t)64 << 10;
 constexpr size_t LANE_CHUNK = (size_t)4 << 20;
 constexpr size_t LANE_COUNT = 4;
 constexpr size_t LANE_THRESHOLD = (size_t)32 << 20;    // smaller transfers go through the runtime
@@ -721,6 +726,7 @@ extern "C" int32_t stark_ctx_create(int32_t device, stark_ctx** out)
     ctx->device = device;
     hipError_t e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipHostMalloc(&ctx->pinned, 4096, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc(&ctx->pin_io, 2 * SMALL_IO_BYTES, hipHostMallocDefault);
     if (e != hipSuccess) {
         delete ctx;
         return fail(STARK_EHIP, std::string("stark_ctx_create: ") + hipGetErrorString(e));
@@ -744,6 +750,7 @@ extern "C" void stark_ctx_destroy(stark_ctx* ctx)
     for (auto& kv : ctx->pool) (void)hipFree(kv.second);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->pin_io) (void)hipHostFree(ctx->pin_io);
     lanes_destroy(ctx);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
@@ -850,6 +857,13 @@ extern "C" int32_t stark_ntt_batch(stark_ctx* ctx, uint64_t* data, size_t n, siz
     if (n_cols == 0) return STARK_OK;
     if (n_cols > 1 && col_stride < n) return fail(STARK_ELENGTH, "column stride smaller than NTT size");
     const size_t span = (n_cols - 1) * col_stride + n;
+    if (span * sizeof(fe) <= SMALL_IO_BYTES) {
+        memcpy(ctx->pin_io, data, span * sizeof(fe));
+        ST_TRY(stark_ntt_batch_dev(ctx, (uint64_t*)ctx->pin_io, n, n_cols, col_stride, inverse));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        memcpy(data, ctx->pin_io, span * sizeof(fe));
+        return STARK_OK;
+    }
     DevBuf buf(ctx);
     ST_TRY(buf.alloc(span * sizeof(fe)));
     HIP_TRY(copy_in(ctx, buf.p, data, span * sizeof(fe)));
@@ -897,6 +911,17 @@ extern "C" int32_t stark_coset_lde_batch(stark_ctx* ctx, const uint64_t* coeffs,
         return fail(STARK_ELENGTH, "stride smaller than column length");
     const size_t in_span = (n_cols - 1) * coeff_stride + n_coeffs;
     const size_t out_span = (n_cols - 1) * out_stride + n_out;
+    if (in_span * sizeof(fe) <= SMALL_IO_BYTES && out_span * sizeof(fe) <= SMALL_IO_BYTES &&
+        (out_stride == n_out || n_cols == 1)) {
+        uint8_t* pin_in = (uint8_t*)ctx->pin_io;
+        uint8_t* pin_out = pin_in + SMALL_IO_BYTES;
+        if (in_span) memcpy(pin_in, coeffs, in_span * sizeof(fe));
+        ST_TRY(stark_coset_lde_batch_dev(ctx, (const uint64_t*)pin_in, n_coeffs, coeff_stride, n_cols, n_out, offset,
+                                         (uint64_t*)pin_out, out_stride));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        memcpy(out, pin_out, out_span * sizeof(fe));
+        return STARK_OK;
+    }
     DevBuf in(ctx), ob(ctx);
     ST_TRY(in.alloc(in_span * sizeof(fe)));
     ST_TRY(ob.alloc(out_span * sizeof(fe)));
