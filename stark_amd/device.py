@@ -320,7 +320,7 @@ class Context:
 
         def _cb(_user, rnd, last, root_p, alpha_out):
             try:
-                root = bytes(root_p[i] for i in range(32))
+                root = C.string_at(root_p, 32)
                 alpha = transcript(int(rnd), bool(last), root)
                 if not last:
                     alpha_out[0] = alpha & 0xFFFFFFFFFFFFFFFF
