@@ -54,6 +54,7 @@ struct NttTables {
     tw5* hi = nullptr;
     tw5* lo = nullptr;
     tw5* fin = nullptr;              // 1, or n^-1 for the inverse
+    int32_t* plane = nullptr;        // outgoing twiddles of the pass before the last, 5 limbs per element (built on first use)
     fe* small = nullptr;             // omega_n^i, i < n/2 (n <= 4096), Montgomery form (2^128)
     fe scale_m{0, 0};                // n^-1, Montgomery form (2^128)
 };
@@ -238,6 +239,9 @@ static std::vector<tw5> powers_5(const HostField& F, fe x, size_t count)
     return v;
 }
 
+// Sizes up to this keep a twiddle plane (20 bytes per element and direction: 1.3 GB at 2^26).
+constexpr uint32_t PLANE_MAX_LOG = 26;
+
 static std::vector<uint32_t> plan_radices(uint32_t log_n)
 {
     std::vector<uint32_t> r;
@@ -408,6 +412,15 @@ static int32_t run_ntt(stark_ctx* ctx, const fe* src, size_t src_stride, size_t 
             } else {
                 a.dst = ctx->scratch;
                 a.dst_batch_stride = n;
+            }
+            if (a.next_is_last && log_n <= PLANE_MAX_LOG) {
+                // the twiddle plane of this pass: 20 bytes per element, built once per size and direction
+                NttTables* tm = const_cast<NttTables*>(t);
+                if (!tm->plane) {
+                    HIP_TRY(hipMalloc((void**)&tm->plane, (size_t)20 << log_n));
+                    HIP_TRY(launch_ntt_plane(a, tm->plane, ctx->stream));
+                }
+                a.plane = tm->plane;
             }
             HIP_TRY(launch_ntt_pass(a, mode, q == 0 && twist != nullptr, (uint32_t)nb, ctx->stream));
         }
@@ -744,7 +757,7 @@ extern "C" void stark_ctx_destroy(stark_ctx* ctx)
     for (auto& kv : ctx->ntt_tables) {
         NttTables& t = kv.second;
         (void)hipFree(t.tw16); (void)hipFree(t.tw256); (void)hipFree(t.hi); (void)hipFree(t.lo); (void)hipFree(t.fin);
-        (void)hipFree(t.small);
+        (void)hipFree(t.small); (void)hipFree(t.plane);
     }
     for (auto& kv : ctx->pow_tables) { (void)hipFree(kv.second.hi); (void)hipFree(kv.second.lo); }
     for (auto& kv : ctx->pool) (void)hipFree(kv.second);

@@ -44,7 +44,13 @@ struct PassArgs {
     uint32_t h;            // log2 of the last radix
     uint32_t nprev;        // q
     uint32_t rprev[MAX_PASSES];   // log2 R_u, u < q
+    // Pass before the last only: its outgoing twiddle omega_n^(j_next * K) has all of n as exponent
+    // range.  If set, plane[5 i .. 5 i + 4] holds the five limbs of the twiddle of output element i
+    // (same index as dst); otherwise the kernel multiplies hi and lo entries together per element.
+    const int32_t* plane;
 };
+// Fills the plane of the pass described by `a` (n = 2^log_n entries of five limbs).
+hipError_t launch_ntt_plane(const PassArgs& a, int32_t* plane, hipStream_t s);
 // All tw5 tables hold Montgomery forms w * 2^156 mod p as five 26-bit limbs.
 
 enum PassMode { PASS_FIRST = 0, PASS_MIDDLE = 1, PASS_LAST = 2 };

@@ -267,7 +267,9 @@ __device__ __forceinline__ void round1_exchange(fe5 (&v)[16], fe5* lds, const tw
 }
 
 // round 2 (radix 16 over jb), outgoing twiddle, store
-template <int RA, int MODE, bool NEXT_LAST>
+// NEXT_LAST: 0 = the next pass is not the last, 1 = it is and the twiddle is formed as hi*lo, 2 = it is
+// and the twiddle comes from the plane
+template <int RA, int MODE, int NEXT_LAST>
 __device__ __forceinline__ void round2_store(fe5 (&v)[16], const PassArgs& a, fe* __restrict__ dst, uint32_t tx,
                                              const tw5* __restrict__ tw16, int t)
 {
@@ -305,7 +307,28 @@ __device__ __forceinline__ void round2_store(fe5 (&v)[16], const PassArgs& a, fe
         // two tables are involved, four elements ahead of their use): a gather
         // issued next to its use would sit behind the previous element's store
         // in the in-order memory counter and expose a full round trip per element.
-        if constexpr (NEXT_LAST) {
+        if constexpr (NEXT_LAST == 2) {
+            {
+                // the twiddle of output element i comes ready-made from the plane: a 20-byte load
+                // next to the store instead of two gathers and a multiplication
+                const int32_t* __restrict__ plane = a.plane;
+                fe5 w[2];
+                auto issue = [&](int kb) {
+                    uint32_t k = ka2 + M1 * kb;
+                    asm volatile("" : "+v"(k));
+                    w[kb & 1] = *(const fe5*)(plane + 5 * (base + ((uint64_t)k << a.log_s)));
+                };
+                ntt_dif_reg<4, 0>(v, tw16);
+                issue(0);
+#pragma clang loop unroll(full)
+                for (int kb = 0; kb < 16; kb++) {
+                    if (kb + 1 < 16) issue(kb + 1);
+                    uint32_t k = ka2 + M1 * kb;
+                    asm volatile("" : "+v"(k));
+                    dst[base + ((uint64_t)k << a.log_s)] = finish(mont_mul5_v(v[brev_c(kb, 4)], w[kb & 1]));
+                }
+            }
+        } else if constexpr (NEXT_LAST == 1) {
             // S_next = 1: exponent j_next * K, split over the hi and lo tables
             constexpr int B = 1;
             tw5 wh[2][B], wl[2][B];
@@ -370,7 +393,32 @@ __device__ __forceinline__ void round2_store(fe5 (&v)[16], const PassArgs& a, fe
 // value; the last pass multiplies by `fin` (1, or n^-1 for the inverse).
 // One workgroup per tile; three workgroups are resident per CU (168 registers,
 // 48-52 KiB of LDS each) and hide one another's memory and barrier waits.
-template <int RA, int MODE, bool TWIST, bool NEXT_LAST>
+// Twiddle plane of the pass before the last (see PassArgs::plane): one thread per output element,
+// the same index arithmetic as round2_store's.
+__global__ __launch_bounds__(256) void ntt_plane_kernel(PassArgs a, int32_t* __restrict__ plane)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >> a.log_n) return;
+    const uint32_t j_next = (uint32_t)(i & (((uint64_t)1 << a.log_s) - 1));
+    const uint32_t k = (uint32_t)(i >> a.log_s) & ((1u << a.r) - 1);
+    const uint32_t pre = (uint32_t)(i >> (a.r + a.log_s));
+    uint32_t bits_prev = 0;
+    for (uint32_t u = 0; u < a.nprev; u++) bits_prev += a.rprev[u];
+    const uint32_t E = j_next * (prefix_to_k(pre, a) + (k << bits_prev));
+    const tw5 wh = a.hi[E >> a.h];
+    const fe5 w = mont_mul5_v(*(const fe5*)&wh, a.lo[E & ((1u << a.h) - 1)]);
+#pragma unroll
+    for (int l = 0; l < 5; l++) plane[5 * i + l] = w.l[l];
+}
+
+hipError_t launch_ntt_plane(const PassArgs& a, int32_t* plane, hipStream_t s)
+{
+    const uint64_t n = (uint64_t)1 << a.log_n;
+    hipLaunchKernelGGL(ntt_plane_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, a, plane);
+    return hipGetLastError();
+}
+
+template <int RA, int MODE, bool TWIST, int NEXT_LAST>
 __global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) void ntt_pass_kernel(PassArgs a)
 {
     using G = Geo<RA, MODE>;
@@ -393,7 +441,7 @@ __global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(3,
     round2_store<RA, MODE, NEXT_LAST>(v, a, a.dst + batch * a.dst_batch_stride, tx, tw16, t);
 }
 
-template <int RA, int MODE, bool TWIST, bool NEXT_LAST>
+template <int RA, int MODE, bool TWIST, int NEXT_LAST>
 static hipError_t launch_one(const PassArgs& a, uint32_t n_batch, hipStream_t s)
 {
     const uint64_t total = (((uint64_t)1 << a.log_n) / TILE_ELEMS) * n_batch;
@@ -405,17 +453,20 @@ static hipError_t launch_one(const PassArgs& a, uint32_t n_batch, hipStream_t s)
 template <int RA>
 static hipError_t launch_ra(const PassArgs& a, PassMode mode, bool twist, uint32_t n_batch, hipStream_t s)
 {
-    const bool nl = a.next_is_last != 0;
+    const int nl = a.next_is_last ? (a.plane ? 2 : 1) : 0;
     switch (mode) {
     case PASS_FIRST:
-        if (twist) return nl ? launch_one<RA, PASS_FIRST, true, true>(a, n_batch, s)
-                             : launch_one<RA, PASS_FIRST, true, false>(a, n_batch, s);
-        return nl ? launch_one<RA, PASS_FIRST, false, true>(a, n_batch, s)
-                  : launch_one<RA, PASS_FIRST, false, false>(a, n_batch, s);
+        if (twist) return nl == 2 ? launch_one<RA, PASS_FIRST, true, 2>(a, n_batch, s)
+                   : nl == 1      ? launch_one<RA, PASS_FIRST, true, 1>(a, n_batch, s)
+                                  : launch_one<RA, PASS_FIRST, true, 0>(a, n_batch, s);
+        return nl == 2 ? launch_one<RA, PASS_FIRST, false, 2>(a, n_batch, s)
+               : nl == 1 ? launch_one<RA, PASS_FIRST, false, 1>(a, n_batch, s)
+                         : launch_one<RA, PASS_FIRST, false, 0>(a, n_batch, s);
     case PASS_MIDDLE:
-        return nl ? launch_one<RA, PASS_MIDDLE, false, true>(a, n_batch, s)
-                  : launch_one<RA, PASS_MIDDLE, false, false>(a, n_batch, s);
-    case PASS_LAST: return launch_one<RA, PASS_LAST, false, false>(a, n_batch, s);
+        return nl == 2 ? launch_one<RA, PASS_MIDDLE, false, 2>(a, n_batch, s)
+               : nl == 1 ? launch_one<RA, PASS_MIDDLE, false, 1>(a, n_batch, s)
+                         : launch_one<RA, PASS_MIDDLE, false, 0>(a, n_batch, s);
+    case PASS_LAST: return launch_one<RA, PASS_LAST, false, 0>(a, n_batch, s);
     }
     return hipErrorInvalidValue;
 }
