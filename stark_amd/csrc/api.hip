@@ -55,6 +55,7 @@ struct NttTables {
     tw5* lo = nullptr;
     tw5* fin = nullptr;              // 1, or n^-1 for the inverse
     int32_t* plane = nullptr;        // outgoing twiddles of the pass before the last, 5 limbs per element (built on first use)
+    bool plane_refused = false;      // the allocation failed once: do not try again
     fe* small = nullptr;             // omega_n^i, i < n/2 (n <= 4096), Montgomery form (2^128)
     fe scale_m{0, 0};                // n^-1, Montgomery form (2^128)
 };
@@ -416,9 +417,14 @@ static int32_t run_ntt(stark_ctx* ctx, const fe* src, size_t src_stride, size_t 
             if (a.next_is_last && log_n <= PLANE_MAX_LOG) {
                 // the twiddle plane of this pass: 20 bytes per element, built once per size and direction
                 NttTables* tm = const_cast<NttTables*>(t);
-                if (!tm->plane) {
-                    HIP_TRY(hipMalloc((void**)&tm->plane, (size_t)20 << log_n));
-                    HIP_TRY(launch_ntt_plane(a, tm->plane, ctx->stream));
+                if (!tm->plane && !tm->plane_refused) {
+                    if (hipMalloc((void**)&tm->plane, (size_t)20 << log_n) != hipSuccess) {
+                        (void)hipGetLastError();          // no room: this size keeps forming hi*lo per element
+                        tm->plane = nullptr;
+                        tm->plane_refused = true;
+                    } else {
+                        HIP_TRY(launch_ntt_plane(a, tm->plane, ctx->stream));
+                    }
                 }
                 a.plane = tm->plane;
             }
