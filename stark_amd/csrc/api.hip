@@ -52,8 +52,7 @@ struct NttTables {
     tw5* tw16 = nullptr;             // multi-pass path: five-limb Montgomery forms (2^156)
     tw5* tw256 = nullptr;
     tw5* hi = nullptr;
-    tw5* lo = nullptr;
-    tw5* fin = nullptr;              // 1, or n^-1 for the inverse
+    tw5* lo = nullptr;               // omega^i, i < 2^h; times n^-1 for the inverse
     int32_t* plane = nullptr;        // outgoing twiddles of the pass before the last, 5 limbs per element (built on first use)
     bool plane_refused = false;      // the allocation failed once: do not try again
     fe* small = nullptr;             // omega_n^i, i < n/2 (n <= 4096), Montgomery form (2^128)
@@ -228,11 +227,11 @@ static tw5 to_tw5(const HostField& F, fe x)
 }
 
 // powers x^0, x^1, ... as five-limb Montgomery forms
-static std::vector<tw5> powers_5(const HostField& F, fe x, size_t count)
+static std::vector<tw5> powers_5(const HostField& F, fe x, size_t count, fe first = fe{1, 0})
 {
     std::vector<tw5> v(count);
     fe xm = F.to_mont(x);
-    fe cur = fe{1, 0};
+    fe cur = first;
     for (size_t i = 0; i < count; i++) {
         v[i] = to_tw5(F, cur);
         cur = mont_mul(cur, xm);       // canonical * Montgomery form -> canonical
@@ -280,9 +279,9 @@ static int32_t get_ntt_tables(stark_ctx* ctx, uint32_t log_n, bool inverse, cons
         ST_TRY(upload(ctx, powers_5(F, w256, 256), &t.tw256));
         fe w_hi = F.pow(omega, (u128)1 << t.h);
         ST_TRY(upload(ctx, powers_5(F, w_hi, (size_t)1 << (log_n - t.h)), &t.hi));
-        ST_TRY(upload(ctx, powers_5(F, omega, (size_t)1 << t.h), &t.lo));
-        std::vector<tw5> fin(1, to_tw5(F, inverse ? n_inv : fe{1, 0}));   // ntt.rs:36-39 folded into the last pass
-        ST_TRY(upload(ctx, fin, &t.fin));
+        // ntt.rs:36-39: the inverse's n^-1 rides on the lo table, which enters exactly one product per
+        // element (the outgoing twiddle of the pass before the last); the last pass multiplies nothing
+        ST_TRY(upload(ctx, powers_5(F, omega, (size_t)1 << t.h, inverse ? n_inv : fe{1, 0}), &t.lo));
     }
     auto ins = ctx->ntt_tables.emplace(key, t);
     *out = &ins.first->second;
@@ -384,7 +383,6 @@ static int32_t run_ntt(stark_ctx* ctx, const fe* src, size_t src_stride, size_t 
             a.tw256 = t->tw256;
             a.hi = t->hi;
             a.lo = t->lo;
-            a.fin = t->fin;
             a.log_n = log_n;
             a.log_s = log_s;
             a.log_s_next = (q + 1 < P) ? log_s - t->radices[q + 1] : 0;
@@ -762,7 +760,7 @@ extern "C" void stark_ctx_destroy(stark_ctx* ctx)
     (void)hipStreamSynchronize(ctx->stream);
     for (auto& kv : ctx->ntt_tables) {
         NttTables& t = kv.second;
-        (void)hipFree(t.tw16); (void)hipFree(t.tw256); (void)hipFree(t.hi); (void)hipFree(t.lo); (void)hipFree(t.fin);
+        (void)hipFree(t.tw16); (void)hipFree(t.tw256); (void)hipFree(t.hi); (void)hipFree(t.lo);
         (void)hipFree(t.small); (void)hipFree(t.plane);
     }
     for (auto& kv : ctx->pow_tables) { (void)hipFree(kv.second.hi); (void)hipFree(kv.second.lo); }

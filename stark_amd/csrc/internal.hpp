@@ -29,8 +29,7 @@ struct PassArgs {
     const tw5* tw16;       // omega_16^i, i<8
     const tw5* tw256;      // omega_256^i, i<256
     const tw5* hi;         // omega_n^(i << h), i < n >> h
-    const tw5* lo;         // omega_n^i, i < 2^h
-    const tw5* fin;        // 1 (forward) or n^-1 (inverse): multiplier of the last pass's outputs
+    const tw5* lo;         // omega_n^i, i < 2^h (times n^-1 for the inverse transform)
     const tw5* twist_hi;   // s^(256 i), first pass of a coset transform
     const tw5* twist_lo;   // s^i, i<256
     uint64_t src_batch_stride;   // elements between consecutive transforms of a batch

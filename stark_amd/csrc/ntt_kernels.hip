@@ -106,6 +106,33 @@ __device__ __forceinline__ void lds_barrier()
 
 // lazy element -> canonical 128-bit value (the slow path is rare: it is taken
 // when the reduced value came out as p + small or small negative)
+// Any lazy limb vector with |value| < 2^134 (the sums of up to sixteen products that leave the last
+// pass's butterflies) -> canonical 128 bits, without a multiplication: q ~ floor(value / p) from the
+// two top limbs, value - q*p = (L - q) + (top - q*P4) * 2^104, one carry sweep, and the exact slow
+// path whenever the top digit does not land in [0, P4) (q off by one, or value = p - 1).
+__device__ __forceinline__ fe finish_lazy(const fe5& x)
+{
+    const int32_t d_top = x.l[4] + (x.l[3] >> LIMB_BITS);
+    const int32_t q = (int32_t)floorf((float)d_top * (1.0f / (float)P4));
+    fe5 r;
+    int32_t c = x.l[0] - q;
+    r.l[0] = c & LIMB_MASK;
+    c >>= LIMB_BITS;
+    c += x.l[1];
+    r.l[1] = c & LIMB_MASK;
+    c >>= LIMB_BITS;
+    c += x.l[2];
+    r.l[2] = c & LIMB_MASK;
+    c >>= LIMB_BITS;
+    c += x.l[3];
+    r.l[3] = c & LIMB_MASK;
+    c >>= LIMB_BITS;
+    r.l[4] = c + x.l[4] - q * P4;
+    fe o = pack_fast(r);
+    if (__builtin_expect((uint32_t)r.l[4] >= (uint32_t)P4, 0)) o = reduce5_slow(x);
+    return o;
+}
+
 __device__ __forceinline__ fe finish(const fe5& x)
 {
     fe o = pack_fast(x);
@@ -284,12 +311,11 @@ __device__ __forceinline__ void round2_store(fe5 (&v)[16], const PassArgs& a, fe
         ntt_dif_reg<4, 0>(v, tw16);
         const uint64_t b = (uint64_t)tx * G::C + c2;
         const uint32_t sh = a.log_n - a.r;
-        const tw5 fin = *a.fin;
 #pragma unroll
         for (int kb = 0; kb < 16; kb++) {
             uint32_t k = ka2 + M1 * kb;
             asm volatile("" : "+v"(k));
-            dst[((uint64_t)k << sh) + b] = finish(mont_mul5_s(v[brev_c(kb, 4)], fin));
+            dst[((uint64_t)k << sh) + b] = finish_lazy(v[brev_c(kb, 4)]);
         }
     } else {
         const uint64_t f = (uint64_t)tx * G::C + c2;
@@ -385,14 +411,6 @@ __device__ __forceinline__ void round2_store(fe5 (&v)[16], const PassArgs& a, fe
     }
 }
 
-// RA = log2(R) - 4.  MODE: PASS_FIRST (strided columns, optional coset twist,
-// zero fill), PASS_MIDDLE (strided columns), PASS_LAST (contiguous rows,
-// transposed store to natural order).  The twiddle that the NEXT pass needs is
-// applied to this pass's outputs, so every element leaves the pass through a
-// multiplication, which is what brings the lazy limbs back to a canonical
-// value; the last pass multiplies by `fin` (1, or n^-1 for the inverse).
-// One workgroup per tile; three workgroups are resident per CU (168 registers,
-// 48-52 KiB of LDS each) and hide one another's memory and barrier waits.
 // Twiddle plane of the pass before the last (see PassArgs::plane): one thread per output element,
 // the same index arithmetic as round2_store's.
 __global__ __launch_bounds__(256) void ntt_plane_kernel(PassArgs a, int32_t* __restrict__ plane)
@@ -418,6 +436,15 @@ hipError_t launch_ntt_plane(const PassArgs& a, int32_t* plane, hipStream_t s)
     return hipGetLastError();
 }
 
+// RA = log2(R) - 4.  MODE: PASS_FIRST (strided columns, optional coset twist,
+// zero fill), PASS_MIDDLE (strided columns), PASS_LAST (contiguous rows,
+// transposed store to natural order).  The twiddle that the NEXT pass needs is
+// applied to this pass's outputs, so every element leaves such a pass through a
+// multiplication, which is what brings the lazy limbs back to a canonical
+// value; the last pass has nothing to multiply by (the inverse's n^-1 rides on
+// the lo table) and reduces its lazy outputs directly (finish_lazy).
+// One workgroup per tile; three workgroups are resident per CU (168 registers,
+// 48-52 KiB of LDS each) and hide one another's memory and barrier waits.
 template <int RA, int MODE, bool TWIST, int NEXT_LAST>
 __global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) void ntt_pass_kernel(PassArgs a)
 {
