@@ -697,3 +697,25 @@ def test_fri_layer_query_equals_reads_and_opens(ctx):
     with pytest.raises(StarkError, match="bad layer"):
         layers.query(len(layers) - 1, [0])
     layers.free()
+
+
+@pytest.mark.parametrize("log_n", [12, 16, 22])
+def test_ntt_structured_inputs(ctx, log_n):
+    """Inputs whose transforms are full of 0, p-1 and exact multiples of p before
+    reduction (constant vectors, a single spike, alternating signs): the
+    reductions of lazy values must stay exact (ntt.rs:25-40)."""
+    n = 1 << log_n
+    cases = {
+        "zeros": np.zeros((n, 2), dtype=np.uint64),
+        "all p-1": np.tile(oc.fe(P - 1), (n, 1)),
+        "all 1": np.tile(oc.fe(1), (n, 1)),
+        "spike p-1 at 0": np.zeros((n, 2), dtype=np.uint64),
+        "spike 1 at n/2": np.zeros((n, 2), dtype=np.uint64),
+        "alternating 1, p-1": np.tile(np.stack([oc.fe(1), oc.fe(P - 1)]), (n // 2, 1)),
+    }
+    cases["spike p-1 at 0"][0] = oc.fe(P - 1)
+    cases["spike 1 at n/2"][n // 2] = oc.fe(1)
+    for name, x in cases.items():
+        x = np.ascontiguousarray(x)
+        for inverse in (False, True):
+            assert np.array_equal(ctx.ntt(x, inverse=inverse), oc.ntt(x, inverse=inverse)), (name, inverse)
