@@ -27,11 +27,11 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak
 # From the rocprofv3 PMC passes kept under profiles/ (r01_ntt22_pmc_{fetch,write,valu}.csv; see
 # profiles/r01_summary.txt), means over the three pass kernels of a 2^22 transform:
 # HBM-side bytes per launch = 2 x FETCH_SIZE (gfx950 counts half of a wide read stream) + WRITE_SIZE
-PMC_TRAFFIC_BYTES_PER_LAUNCH = (2 * 47940 + 65536) * 1024     # 28 MB of it is the middle pass's twiddle plane
+PMC_TRAFFIC_BYTES_PER_LAUNCH = (2 * 47915 + 65536) * 1024     # 28 MB of it is the middle pass's twiddle plane
 # 64-bit-class VALU wave-instructions per launch (v_mad_i64_i32 and the 64-bit shifts/adds of the
 # Montgomery product), and all VALU wave-instructions per launch
-PMC_INT64_WAVE_INSTR_PER_LAUNCH = 10556757
-PMC_VALU_WAVE_INSTR_PER_LAUNCH = 18429269
+PMC_INT64_WAVE_INSTR_PER_LAUNCH = 9661099
+PMC_VALU_WAVE_INSTR_PER_LAUNCH = 17555456
 # a SIMD issues one 64-bit-class integer instruction per 4 cycles: 1024 SIMDs x 2.4 GHz / 4
 VALU_INT64_PEAK_GINSTR_S = 1024 * 2.4 / 4
 
