@@ -60,6 +60,11 @@ void stark_ctx_destroy(stark_ctx* ctx);
 int32_t stark_ctx_set_stream(stark_ctx* ctx, void* hip_stream);
 int32_t stark_ctx_reset_stream(stark_ctx* ctx);
 int32_t stark_ctx_synchronize(stark_ctx* ctx);
+/* Releases the device memory a context keeps between calls for speed (cached
+ * scratch blocks of up to 8 GiB in total, the transform's ping buffer, twiddle
+ * tables and planes); everything is rebuilt on next use.  The library also does
+ * this by itself before it reports STARK_ENOMEM. */
+int32_t stark_ctx_trim(stark_ctx* ctx);
 const char* stark_last_error(void);
 
 /* ---- device memory helpers (for callers that keep vectors resident) ------ */

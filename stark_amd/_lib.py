@@ -27,6 +27,7 @@ SIGNATURES = {
     "stark_ctx_set_stream": (i32, [C.c_void_p, C.c_void_p]),
     "stark_ctx_reset_stream": (i32, [C.c_void_p]),
     "stark_ctx_synchronize": (i32, [C.c_void_p]),
+    "stark_ctx_trim": (i32, [C.c_void_p]),
     "stark_dev_alloc": (i32, [C.c_void_p, sz, voidpp]),
     "stark_dev_free": (i32, [C.c_void_p, C.c_void_p]),
     "stark_copy_h2d": (i32, [C.c_void_p, C.c_void_p, C.c_void_p, sz]),

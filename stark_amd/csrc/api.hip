@@ -61,11 +61,24 @@ struct NttTables {
 
 // powers of one element x: lo[i] = x^i (i<256), hi[i] = x^(256 i); either as
 // 16-byte Montgomery forms (2^128) or as five-limb forms (2^156)
+// Handed out as shared pointers: a commit keeps its tables alive across the transcript callback
+// (which may call back into the same context and push other tables through the bounded cache), and
+// the device memory goes when the last holder lets go.
 struct PowTables {
     void* hi = nullptr;
     void* lo = nullptr;
     size_t hi_len = 0;
+    uint64_t stamp = 0;                                // last use, for eviction
+    PowTables() = default;
+    PowTables(const PowTables&) = delete;
+    PowTables& operator=(const PowTables&) = delete;
+    ~PowTables()
+    {
+        if (hi) (void)hipFree(hi);
+        if (lo) (void)hipFree(lo);
+    }
 };
+typedef std::shared_ptr<PowTables> PowRef;
 
 typedef std::tuple<uint64_t, uint64_t, uint64_t, int> PowKey;   // (x.lo, x.hi, hi_len, five-limb?)
 
@@ -77,10 +90,12 @@ struct stark_ctx {
     hipStream_t stream = nullptr;
     HostField F;
     std::map<uint32_t, NttTables> ntt_tables;          // key = log_n*2 + inverse
-    std::map<PowKey, PowTables> pow_tables;
+    std::map<PowKey, PowRef> pow_tables;
+    uint64_t pow_clock = 0;
     fe* scratch = nullptr;
     size_t scratch_elems = 0;
     std::multimap<size_t, void*> pool;                 // cached device blocks by size
+    size_t pool_large_bytes = 0;                       // bytes of the cached blocks of at least 1 MiB
     void* pinned = nullptr;                            // small pinned staging buffer (4 KiB)
     void* pin_io = nullptr;                            // 2 x 64 KiB host-mapped: small transforms run on it in place
     std::recursive_mutex mu;
@@ -155,6 +170,31 @@ static size_t pool_bucket(size_t bytes)
     return b;
 }
 
+// Blocks of at least 1 MiB that the cache may hold: a count and a byte total (a 2^24 FRI commit
+// parks a 0.5 GiB and a 2 GiB arena, a 2^26 one 2 + 8 GiB).
+constexpr size_t POOL_LARGE = (size_t)1 << 20;
+constexpr size_t POOL_MAX_LARGE_BLOCKS = 16;
+constexpr size_t POOL_MAX_LARGE_BYTES = (size_t)8 << 30;
+
+static void pool_drop(stark_ctx* ctx)
+{
+    for (auto& kv : ctx->pool) (void)hipFree(kv.second);
+    ctx->pool.clear();
+    ctx->pool_large_bytes = 0;
+}
+
+// hipMalloc that gives the cached blocks back to the runtime and retries once when memory is short
+static hipError_t malloc_retry(stark_ctx* ctx, void** out, size_t bytes)
+{
+    hipError_t e = hipMalloc(out, bytes);
+    if (e == hipErrorOutOfMemory && !ctx->pool.empty()) {
+        (void)hipGetLastError();
+        pool_drop(ctx);
+        e = hipMalloc(out, bytes);
+    }
+    return e;
+}
+
 static int32_t pool_alloc(stark_ctx* ctx, size_t bytes, void** out)
 {
     bytes = pool_bucket(bytes);
@@ -162,15 +202,10 @@ static int32_t pool_alloc(stark_ctx* ctx, size_t bytes, void** out)
     if (it != ctx->pool.end()) {
         *out = it->second;
         ctx->pool.erase(it);
+        if (bytes >= POOL_LARGE) ctx->pool_large_bytes -= bytes;
         return STARK_OK;
     }
-    hipError_t e = hipMalloc(out, bytes);
-    if (e != hipSuccess) {
-        // drop the cache and retry once
-        for (auto& kv : ctx->pool) (void)hipFree(kv.second);
-        ctx->pool.clear();
-        e = hipMalloc(out, bytes);
-    }
+    hipError_t e = malloc_retry(ctx, out, bytes);
     if (e != hipSuccess) return fail(STARK_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
     return STARK_OK;
 }
@@ -179,23 +214,32 @@ static void pool_free(stark_ctx* ctx, void* p, size_t bytes)
 {
     if (!p) return;
     bytes = pool_bucket(bytes);
-    // keep at most a handful of large blocks (they can be gigabytes) and a few hundred small ones
-    size_t large = 0;
-    if (bytes >= ((size_t)1 << 20))
-        for (auto& kv : ctx->pool) large += kv.first >= ((size_t)1 << 20);
-    if (large >= 16 || ctx->pool.size() >= 512) {
+    // keep at most a handful of large blocks, bounded in bytes too, and a few hundred small ones
+    bool keep = ctx->pool.size() < 512;
+    if (keep && bytes >= POOL_LARGE) {
+        size_t large = 0;
+        for (auto& kv : ctx->pool) large += kv.first >= POOL_LARGE;
+        keep = large < POOL_MAX_LARGE_BLOCKS && ctx->pool_large_bytes + bytes <= POOL_MAX_LARGE_BYTES;
+    }
+    if (!keep) {
         (void)hipFree(p);
         return;
     }
     ctx->pool.emplace(bytes, p);
+    if (bytes >= POOL_LARGE) ctx->pool_large_bytes += bytes;
 }
 
 template <class T>
 static int32_t upload(stark_ctx* ctx, const std::vector<T>& v, T** out)
 {
-    HIP_TRY(hipMalloc((void**)out, v.size() * sizeof(T)));
-    HIP_TRY(hipMemcpy(*out, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
-    (void)ctx;
+    *out = nullptr;
+    HIP_TRY(malloc_retry(ctx, (void**)out, v.size() * sizeof(T)));
+    hipError_t e = hipMemcpy(*out, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(*out);
+        *out = nullptr;
+        HIP_TRY(e);
+    }
     return STARK_OK;
 }
 
@@ -252,6 +296,15 @@ static std::vector<uint32_t> plan_radices(uint32_t log_n)
     return r;
 }
 
+static void free_ntt_tables(NttTables& t)
+{
+    (void)hipFree(t.tw16); (void)hipFree(t.tw256); (void)hipFree(t.hi); (void)hipFree(t.lo);
+    (void)hipFree(t.small); (void)hipFree(t.plane);
+    t.tw16 = t.tw256 = t.hi = t.lo = nullptr;
+    t.small = nullptr;
+    t.plane = nullptr;
+}
+
 static int32_t get_ntt_tables(stark_ctx* ctx, uint32_t log_n, bool inverse, const NttTables** out)
 {
     uint32_t key = log_n * 2 + (inverse ? 1 : 0);
@@ -267,56 +320,62 @@ static int32_t get_ntt_tables(stark_ctx* ctx, uint32_t log_n, bool inverse, cons
     if (inverse) omega = F.inverse(omega);                    // ntt.rs:19
     fe n_inv = F.inverse(fe{(u64)1 << log_n, 0});             // ntt.rs:36
     t.scale_m = F.to_mont(n_inv);
+    int32_t rc = STARK_OK;
     if (log_n < (uint32_t)PASS_MIN_LOG) {
         size_t half = log_n ? ((size_t)1 << (log_n - 1)) : 1;
-        ST_TRY(upload(ctx, powers_m(F, omega, half), &t.small));
+        rc = upload(ctx, powers_m(F, omega, half), &t.small);
     } else {
         t.radices = plan_radices(log_n);
         t.h = t.radices.back();
         fe w16 = F.pow(omega, (u128)1 << (log_n - 4));
         fe w256 = F.pow(omega, (u128)1 << (log_n - 8));
-        ST_TRY(upload(ctx, powers_5(F, w16, 8), &t.tw16));
-        ST_TRY(upload(ctx, powers_5(F, w256, 256), &t.tw256));
         fe w_hi = F.pow(omega, (u128)1 << t.h);
-        ST_TRY(upload(ctx, powers_5(F, w_hi, (size_t)1 << (log_n - t.h)), &t.hi));
+        rc = upload(ctx, powers_5(F, w16, 8), &t.tw16);
+        if (rc == STARK_OK) rc = upload(ctx, powers_5(F, w256, 256), &t.tw256);
+        if (rc == STARK_OK) rc = upload(ctx, powers_5(F, w_hi, (size_t)1 << (log_n - t.h)), &t.hi);
         // ntt.rs:36-39: the inverse's n^-1 rides on the lo table, which enters exactly one product per
         // element (the outgoing twiddle of the pass before the last); the last pass multiplies nothing
-        ST_TRY(upload(ctx, powers_5(F, omega, (size_t)1 << t.h, inverse ? n_inv : fe{1, 0}), &t.lo));
+        if (rc == STARK_OK) rc = upload(ctx, powers_5(F, omega, (size_t)1 << t.h, inverse ? n_inv : fe{1, 0}), &t.lo);
+    }
+    if (rc != STARK_OK) {
+        free_ntt_tables(t);                                   // nothing half-built stays behind
+        return rc;
     }
     auto ins = ctx->ntt_tables.emplace(key, t);
     *out = &ins.first->second;
     return STARK_OK;
 }
 
-static int32_t get_pow_tables(stark_ctx* ctx, fe x, size_t count, bool five, const PowTables** out)
+static int32_t get_pow_tables(stark_ctx* ctx, fe x, size_t count, bool five, PowRef* out)
 {
     size_t hi_len = (count + 255) / 256;
     if (hi_len == 0) hi_len = 1;
     PowKey key(x.lo, x.hi, hi_len, five ? 1 : 0);
     auto it = ctx->pow_tables.find(key);
     if (it != ctx->pow_tables.end()) {
-        *out = &it->second;
+        it->second->stamp = ++ctx->pow_clock;
+        *out = it->second;
         return STARK_OK;
     }
-    if (ctx->pow_tables.size() >= 32) {                       // bounded cache
-        for (auto& kv : ctx->pow_tables) {
-            (void)hipFree(kv.second.hi);
-            (void)hipFree(kv.second.lo);
-        }
-        ctx->pow_tables.clear();
+    while (ctx->pow_tables.size() >= 32) {                    // bounded cache: drop the least recently used entry;
+        auto victim = ctx->pow_tables.begin();                // whoever still holds it keeps it alive
+        for (auto jt = ctx->pow_tables.begin(); jt != ctx->pow_tables.end(); ++jt)
+            if (jt->second->stamp < victim->second->stamp) victim = jt;
+        ctx->pow_tables.erase(victim);
     }
     const HostField& F = ctx->F;
-    PowTables t;
-    t.hi_len = hi_len;
+    PowRef t = std::make_shared<PowTables>();                 // a failed upload below frees what was uploaded
+    t->hi_len = hi_len;
+    t->stamp = ++ctx->pow_clock;
     if (five) {
-        ST_TRY(upload(ctx, powers_5(F, x, 256), (tw5**)&t.lo));
-        ST_TRY(upload(ctx, powers_5(F, F.pow(x, 256), hi_len), (tw5**)&t.hi));
+        ST_TRY(upload(ctx, powers_5(F, x, 256), (tw5**)&t->lo));
+        ST_TRY(upload(ctx, powers_5(F, F.pow(x, 256), hi_len), (tw5**)&t->hi));
     } else {
-        ST_TRY(upload(ctx, powers_m(F, x, 256), (fe**)&t.lo));
-        ST_TRY(upload(ctx, powers_m(F, F.pow(x, 256), hi_len), (fe**)&t.hi));
+        ST_TRY(upload(ctx, powers_m(F, x, 256), (fe**)&t->lo));
+        ST_TRY(upload(ctx, powers_m(F, F.pow(x, 256), hi_len), (fe**)&t->hi));
     }
-    auto ins = ctx->pow_tables.emplace(key, t);
-    *out = &ins.first->second;
+    ctx->pow_tables.emplace(key, t);
+    *out = t;
     return STARK_OK;
 }
 
@@ -329,7 +388,7 @@ static int32_t ensure_scratch(stark_ctx* ctx, size_t elems)
         ctx->scratch = nullptr;
         ctx->scratch_elems = 0;
     }
-    HIP_TRY(hipMalloc((void**)&ctx->scratch, elems * sizeof(fe)));
+    HIP_TRY(malloc_retry(ctx, (void**)&ctx->scratch, elems * sizeof(fe)));
     ctx->scratch_elems = elems;
     return STARK_OK;
 }
@@ -344,7 +403,7 @@ static int32_t run_ntt(stark_ctx* ctx, const fe* src, size_t src_stride, size_t 
     const NttTables* t;
     ST_TRY(get_ntt_tables(ctx, log_n, inverse, &t));
     const size_t n = (size_t)1 << log_n;
-    const PowTables* twist = nullptr;
+    PowRef twist;
     if (twist_x) ST_TRY(get_pow_tables(ctx, *twist_x, n_src, log_n >= (uint32_t)PASS_MIN_LOG, &twist));
     if (log_n < (uint32_t)PASS_MIN_LOG) {
         SmallArgs a{};
@@ -420,8 +479,11 @@ static int32_t run_ntt(stark_ctx* ctx, const fe* src, size_t src_stride, size_t 
                         (void)hipGetLastError();          // no room: this size keeps forming hi*lo per element
                         tm->plane = nullptr;
                         tm->plane_refused = true;
-                    } else {
-                        HIP_TRY(launch_ntt_plane(a, tm->plane, ctx->stream));
+                    } else if (launch_ntt_plane(a, tm->plane, ctx->stream) != hipSuccess) {
+                        (void)hipGetLastError();          // an unfilled plane must never be read
+                        (void)hipFree(tm->plane);
+                        tm->plane = nullptr;
+                        tm->plane_refused = true;
                     }
                 }
                 a.plane = tm->plane;
@@ -758,13 +820,9 @@ extern "C" void stark_ctx_destroy(stark_ctx* ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    for (auto& kv : ctx->ntt_tables) {
-        NttTables& t = kv.second;
-        (void)hipFree(t.tw16); (void)hipFree(t.tw256); (void)hipFree(t.hi); (void)hipFree(t.lo);
-        (void)hipFree(t.small); (void)hipFree(t.plane);
-    }
-    for (auto& kv : ctx->pow_tables) { (void)hipFree(kv.second.hi); (void)hipFree(kv.second.lo); }
-    for (auto& kv : ctx->pool) (void)hipFree(kv.second);
+    for (auto& kv : ctx->ntt_tables) free_ntt_tables(kv.second);
+    ctx->pow_tables.clear();
+    pool_drop(ctx);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->pin_io) (void)hipHostFree(ctx->pin_io);
@@ -803,7 +861,24 @@ extern "C" int32_t stark_dev_alloc(stark_ctx* ctx, size_t bytes, void** dptr)
 {
     CtxGuard guard_(ctx);
     if (!ctx || !dptr) return fail(STARK_EARG, "null argument");
-    HIP_TRY(hipMalloc(dptr, bytes ? bytes : 16));
+    HIP_TRY(malloc_retry(ctx, dptr, bytes ? bytes : 16));
+    return STARK_OK;
+}
+
+// Gives back what the context keeps between calls for speed: the cached scratch blocks, the ping
+// buffer of the multi-pass transform and the twiddle planes (tables and planes are rebuilt on next use).
+extern "C" int32_t stark_ctx_trim(stark_ctx* ctx)
+{
+    CtxGuard guard_(ctx);
+    if (!ctx) return fail(STARK_EARG, "null context");
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    pool_drop(ctx);
+    if (ctx->scratch) (void)hipFree(ctx->scratch);
+    ctx->scratch = nullptr;
+    ctx->scratch_elems = 0;
+    for (auto& kv : ctx->ntt_tables) free_ntt_tables(kv.second);
+    ctx->ntt_tables.clear();
+    ctx->pow_tables.clear();
     return STARK_OK;
 }
 
@@ -994,7 +1069,7 @@ extern "C" int32_t stark_fourstep_twiddle_dev(stark_ctx* ctx, uint64_t* data_dev
         return fail(STARK_ELENGTH, "twiddle block exceeds the transform size");
     fe w = ctx->F.primitive_nth_root((unsigned)log_n);
     if (inverse) w = ctx->F.inverse(w);
-    const PowTables* pt;
+    PowRef pt;
     ST_TRY(get_pow_tables(ctx, w, n_total, false, &pt));
     HIP_TRY(launch_fourstep_twiddle((fe*)data_dev, row_start, n_rows, n_cols, (const fe*)pt->hi, (const fe*)pt->lo,
                                     ctx->stream));
@@ -1107,7 +1182,7 @@ extern "C" size_t stark_fri_num_rounds(size_t domain_length, size_t expansion_fa
 }
 
 // power tables of omega^-1 covering exponents < N
-static int32_t fold_tables(stark_ctx* ctx, fe omega, size_t N, const PowTables** out)
+static int32_t fold_tables(stark_ctx* ctx, fe omega, size_t N, PowRef* out)
 {
     return get_pow_tables(ctx, ctx->F.inverse(omega), N, false, out);
 }
@@ -1127,7 +1202,7 @@ extern "C" int32_t stark_fri_fold_dev(stark_ctx* ctx, const uint64_t* codeword_d
     if (N < 2 || (N & 1)) return fail(STARK_ELENGTH, "codeword length must be even");
     fe al{alpha[0], alpha[1]}, of{offset[0], offset[1]}, om{omega[0], omega[1]};
     if (!is_canonical(al) || !is_canonical(of) || !is_canonical(om)) return fail(STARK_EARG, "scalar not reduced modulo p");
-    const PowTables* pt;
+    PowRef pt;
     ST_TRY(fold_tables(ctx, om, N / 2, &pt));
     FoldArgs a{};
     a.cw = (const fe*)codeword_dev;
@@ -1160,7 +1235,7 @@ extern "C" int32_t stark_fri_fold_shard_dev(stark_ctx* ctx, const uint64_t* loca
     fe al{alpha[0], alpha[1]}, of{offset[0], offset[1]}, om{omega[0], omega[1]};
     if (!is_canonical(al) || !is_canonical(of) || !is_canonical(om)) return fail(STARK_EARG, "scalar not reduced modulo p");
     const size_t half = local_len / 2, chunks_out = half / chunk_len;
-    const PowTables* pt;
+    PowRef pt;
     ST_TRY(fold_tables(ctx, om, chunks_out * period, &pt));     // positions of the outputs are < (layer length)/2
     FoldArgs a{};
     a.cw = (const fe*)local_dev;
@@ -1275,7 +1350,7 @@ static int32_t fri_commit_impl(stark_ctx* ctx, const fe* cw_src, bool src_is_hos
             return cleanup(fail(STARK_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_))); \
     } while (0)
 
-    const PowTables* pt;
+    PowRef pt;
     rc = fold_tables(ctx, om, N / 2, &pt);
     if (rc != STARK_OK) return cleanup(rc);
 

@@ -7,6 +7,7 @@ device memory and streams; nothing here imports it."""
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 from typing import Callable, List, Optional, Sequence
 
 import numpy as np
@@ -49,6 +50,7 @@ class Tree:
 
     def __init__(self, ctx: "Context", handle):
         self.ctx, self.h = ctx, handle
+        ctx._track(self)
 
     @property
     def num_leaves(self) -> int:
@@ -79,9 +81,11 @@ class Tree:
         return out
 
     def free(self):
-        if self.h:
+        # a handle locks its context when it is freed: after Context.close() (which frees the handles
+        # still alive) there is nothing left to do
+        if self.h and self.ctx.h:
             self.ctx.lib.stark_tree_free(self.h)
-            self.h = None
+        self.h = None
 
     def __del__(self):
         try:
@@ -95,6 +99,7 @@ class FriLayers:
 
     def __init__(self, ctx: "Context", handle):
         self.ctx, self.h = ctx, handle
+        ctx._track(self)
 
     def __len__(self):
         return self.ctx.lib.stark_fri_layers_count(self.h)
@@ -154,9 +159,9 @@ class FriLayers:
         return vals[:, :t], cut(0, d), cut(t * d, d), cut(2 * t * d, dn)
 
     def free(self):
-        if self.h:
+        if self.h and self.ctx.h:
             self.ctx.lib.stark_fri_layers_free(self.h)
-            self.h = None
+        self.h = None
 
     def __del__(self):
         try:
@@ -174,15 +179,27 @@ class Context:
             raise StarkError(rc, self.lib.stark_last_error().decode())
         self.h = h
         self.device = device
+        self._handles: "weakref.WeakSet" = weakref.WeakSet()     # trees and layers that belong to this context
 
     def _chk(self, rc: int):
         if rc:
             raise StarkError(rc, self.lib.stark_last_error().decode())
 
+    def _track(self, handle):
+        self._handles.add(handle)
+
     def close(self):
+        """Frees the trees and layers still alive on this context, then the context (their handles
+        point into it, so none may outlive it)."""
         if self.h:
+            for handle in list(self._handles):
+                handle.free()
             self.lib.stark_ctx_destroy(self.h)
             self.h = None
+
+    def trim(self):
+        """Give cached device memory (scratch blocks, tables, planes) back to the runtime."""
+        self._chk(self.lib.stark_ctx_trim(self.h))
 
     def set_stream(self, hip_stream: Optional[int]):
         """Launch on the caller's stream (None / 0 = HIP's default stream)."""

@@ -34,32 +34,52 @@ class HipEngine:
 
     def __init__(self, ctx):
         self.ctx = ctx
+        self._bound = None
+
+    def _bind(self, t: torch.Tensor) -> None:
+        """The library launches on the context's stream; the tensors it is handed were produced by
+        torch ops and collectives on torch's current stream, and its results are consumed there.
+        Every engine call therefore first points the context at torch's current stream for the
+        tensor's device (it may have changed under `with torch.cuda.stream(s)`), which orders the
+        two by plain stream order.  Switching synchronises the stream the context leaves."""
+        if not t.is_cuda:
+            return
+        cur = torch.cuda.current_stream(t.device).cuda_stream
+        if cur != self._bound:
+            self.ctx.set_stream(cur)
+            self._bound = cur
 
     def ntt_batch(self, t: torch.Tensor, inverse: bool) -> None:
+        self._bind(t)
         cols, n, _ = t.shape
         self.ctx.ntt_dev(t, n, inverse=inverse, n_cols=cols, col_stride=n)
 
     def twiddle(self, t: torch.Tensor, n_total: int, row_start: int, inverse: bool) -> None:
+        self._bind(t)
         rows, cols, _ = t.shape
         self.ctx.fourstep_twiddle_dev(t, n_total, row_start, rows, cols, inverse=inverse)
 
     def coset_lde(self, coeffs: torch.Tensor, n_out: int, offset: int) -> torch.Tensor:
+        self._bind(coeffs)
         cols, n_coeffs, _ = coeffs.shape
         out = torch.empty((cols, n_out, 2), dtype=coeffs.dtype, device=coeffs.device)
         self.ctx.coset_lde_batch_dev(coeffs, n_coeffs, n_coeffs, cols, n_out, offset, out, n_out)
         return out
 
     def merkle_root(self, column: torch.Tensor) -> bytes:
+        self._bind(column)
         return self.ctx.merkle_commit_fe_dev(column, column.shape[0])
 
     def merkle_roots(self, columns: torch.Tensor) -> List[bytes]:
         """Roots of all columns of a contiguous (cols, n, 2) batch in one call."""
+        self._bind(columns)
         cols, n, _ = columns.shape
         return self.ctx.merkle_roots_fe_batch_dev(columns, n, cols, n)
 
     # ---- sharded FRI commit ------------------------------------------------
     def subtree_roots(self, local: torch.Tensor, chunk_len: int, keep: bool = False):
         """(roots (n_chunks, 32) on the device, forest handle or None)."""
+        self._bind(local)
         n_chunks = local.shape[0] // chunk_len
         roots = torch.empty((n_chunks, 32), dtype=torch.uint8, device=local.device)
         forest = self.ctx.merkle_subtree_roots_dev(local, chunk_len, n_chunks, roots, keep_forest=keep)
@@ -67,11 +87,13 @@ class HipEngine:
 
     def root_of_digests(self, digests: torch.Tensor, keep: bool = False):
         """root, or (root, tree handle) with keep."""
+        self._bind(digests)
         return self.ctx.merkle_root_of_digests_dev(digests, digests.shape[0], keep_tree=keep)
 
     def fold_shard(self, local: torch.Tensor, alpha: int, offset: int, omega: int, chunk_len: int, period: int,
                    base: int, want_roots: bool, keep: bool = False):
         """(folded share, its chunk roots or None, forest handle or None)."""
+        self._bind(local)
         half = local.shape[0] // 2
         out = torch.empty((half, 2), dtype=local.dtype, device=local.device)
         roots = torch.empty((half // chunk_len, 32), dtype=torch.uint8, device=local.device) if want_roots else None
@@ -89,6 +111,7 @@ class HipEngine:
 
     def fri_commit(self, codeword: torch.Tensor, offset: int, omega: int, expansion_factor: int,
                    num_colinearity_tests: int, transcript):
+        self._bind(codeword)
         return self.ctx.fri_commit(codeword, offset, omega, expansion_factor, num_colinearity_tests, transcript,
                                    n=codeword.shape[0])
 

@@ -82,10 +82,13 @@ class Stream:
     """ProofStream (proof_stream.rs:8-69) held by the C++ mirror."""
 
     def __init__(self, handle=None):
+        self.h = None
         self.h = _vp(handle) if handle else _vp(lib.sh_ps_new())
 
     def __del__(self):
-        lib.sh_ps_free(self.h)
+        if getattr(self, "h", None):
+            lib.sh_ps_free(self.h)
+            self.h = None
 
     def push(self, s):
         b = s.encode()

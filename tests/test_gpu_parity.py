@@ -148,6 +148,30 @@ def test_coset_lde_full_size_column(ctx):
     assert np.array_equal(out, oc.coset_lde(c, 1 << 22, G))
 
 
+def test_batched_lde_commit_full_size_64_columns(ctx):
+    """The batched workload at its real size (the per-register loop of stark.rs:293-306 over 64
+    columns): 64 x 2^20 coefficients -> 64 x 2^22 evaluations on generator * omega^i and one Merkle
+    root per column, in one coset_lde_batch_dev and one merkle_roots_fe_batch_dev.  At this size the
+    transform runs in scratch-bounded groups of 16 columns and the commitments in groups of trees
+    that fit 4 GiB.  First, middle and last column and their roots against the CPU restatement."""
+    import torch
+    cols, n_coeffs, n_out = 64, 1 << 20, 1 << 22
+    host = oc.splitmix(cols * n_coeffs, 333).reshape(cols, n_coeffs, 2)
+    coeffs = torch.from_numpy(host.view(np.int64)).cuda()
+    out = torch.empty((cols, n_out, 2), dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    ctx.coset_lde_batch_dev(coeffs, n_coeffs, n_coeffs, cols, n_out, G, out, n_out)
+    roots = ctx.merkle_roots_fe_batch_dev(out, n_out, cols, n_out)       # returns after a synchronisation
+    assert len(roots) == cols and len(set(roots)) == cols
+    for c in (0, cols // 2, cols - 1):
+        want = oc.coset_lde(np.ascontiguousarray(host[c]), n_out, G)
+        got = out[c].cpu().numpy().view(np.uint64)
+        assert np.array_equal(got, want), f"column {c}"
+        assert roots[c] == oc.merkle_commit_fe(want), f"root {c}"
+    del coeffs, out
+    torch.cuda.empty_cache()
+
+
 # ---- Merkle (merkle.rs) ----------------------------------------------------------
 @pytest.mark.parametrize("log_n", [0, 1, 2, 3, 5, 10, 11, 12, 13, 16])
 def test_merkle_commit_fe_vs_oracle(ctx, log_n):
