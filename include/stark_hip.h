@@ -40,7 +40,7 @@ typedef struct stark_fri_layers stark_fri_layers; /* codewords + trees of one Fr
 enum {
     STARK_OK = 0,
     STARK_ENOTPOW2 = 1,   /* "NTT size must be power of 2" / "length must be power of two" */
-    STARK_ETOOLARGE = 2,  /* "NTT size too large for practical use" (ntt.rs:16) */
+    STARK_ETOOLARGE = 2,  /* "NTT size too large for practical use" (ntt.rs:16); input beyond a stated maximum */
     STARK_ELENGTH = 3,    /* "Input size must match NTT size" and other length mismatches */
     STARK_EINDEX = 4,     /* "cannot open invalid index" (merkle.rs:56) */
     STARK_EROUNDS = 5,    /* "Cannot do FRI with less than 1 round" (fri.rs:34) */
@@ -127,6 +127,16 @@ int32_t stark_merkle_commit_fe_dev(stark_ctx* ctx, const uint64_t* elems_dev, si
  * (host).  All columns go through the same launches; trees are not retained. */
 int32_t stark_merkle_roots_fe_batch_dev(stark_ctx* ctx, const uint64_t* elems_dev, size_t n, size_t n_cols,
                                         size_t col_stride, uint8_t* roots_out);
+/* No counterpart in the reference.  For callers that cannot allocate (code under
+ * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc): the
+ * root that stark_merkle_commit_fe_dev computes, with the tree built in a static
+ * device array inside the library (16 MiB per GPU, held until the process ends)
+ * instead of allocated memory.  n must be a power of two and at most 2^18
+ * (STARK_ETOOLARGE beyond); root_dev_out is 32 bytes of device-accessible memory.
+ * The call allocates and frees nothing and is not synchronised.  Every call a
+ * process makes on one GPU uses that GPU's one array, which keeps the last
+ * call's tree: calls that overlap on a GPU (two streams, two contexts) race. */
+int32_t stark_merkle_root_fe_static_dev(stark_ctx* ctx, const uint64_t* elems_dev, size_t n, uint8_t* root_dev_out);
 /* A Merkle tree cut across devices.  Merkle::commit pairs nodes (2i, 2i+1)
  * level by level (merkle.rs:38-51), so every aligned run of chunk_len leaves
  * (a power of two) is a subtree of its own: a device that holds n_chunks such

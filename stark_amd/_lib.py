@@ -44,6 +44,7 @@ SIGNATURES = {
     "stark_merkle_commit_fe": (i32, [C.c_void_p, C.c_void_p, sz, u8p, voidpp]),
     "stark_merkle_commit_fe_dev": (i32, [C.c_void_p, C.c_void_p, sz, u8p, voidpp]),
     "stark_merkle_roots_fe_batch_dev": (i32, [C.c_void_p, C.c_void_p, sz, sz, sz, C.c_void_p]),
+    "stark_merkle_root_fe_static_dev": (i32, [C.c_void_p, C.c_void_p, sz, C.c_void_p]),
     "stark_merkle_subtree_roots_dev": (i32, [C.c_void_p, C.c_void_p, sz, sz, C.c_void_p, voidpp]),
     "stark_merkle_root_of_digests_dev": (i32, [C.c_void_p, C.c_void_p, sz, u8p, voidpp]),
     "stark_merkle_commit_bytes": (i32, [C.c_void_p, C.c_void_p, C.c_void_p, sz, u8p, voidpp]),

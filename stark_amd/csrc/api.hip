@@ -84,8 +84,16 @@ typedef std::tuple<uint64_t, uint64_t, uint64_t, int> PowKey;   // (x.lo, x.hi, 
 
 }  // namespace
 
+// Scratch of stark_merkle_root_fe_static_dev: the whole tree of up to STATIC_TREE_MAX_LEAVES leaves
+// (2n - 1 digests of 32 bytes), 16 MiB that every GPU this library runs on holds until the process
+// ends.  Host code never uses this name as an address: stark_ctx_create asks the runtime for the
+// array's address on the context's device and keeps it in stark_ctx::static_scratch.
+constexpr size_t STATIC_TREE_MAX_LEAVES = (size_t)1 << 18;
+static __device__ __align__(256) unsigned char scratch[2 * STATIC_TREE_MAX_LEAVES * sizeof(digest)];
+
 struct stark_ctx {
     int device = 0;
+    void* static_scratch = nullptr;                    // device address of `scratch` on this context's device
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     HostField F;
@@ -806,6 +814,9 @@ extern "C" int32_t stark_ctx_create(int32_t device, stark_ctx** out)
     hipError_t e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipHostMalloc(&ctx->pinned, 4096, hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc(&ctx->pin_io, 2 * SMALL_IO_BYTES, hipHostMallocDefault);
+    // each GPU holds its own copy of the static scratch array at its own address (the device was
+    // made current above)
+    if (e == hipSuccess) e = hipGetSymbolAddress(&ctx->static_scratch, HIP_SYMBOL(scratch));
     if (e != hipSuccess) {
         delete ctx;
         return fail(STARK_EHIP, std::string("stark_ctx_create: ") + hipGetErrorString(e));
@@ -1085,6 +1096,26 @@ extern "C" int32_t stark_merkle_commit_fe_dev(stark_ctx* ctx, const uint64_t* el
     CtxGuard guard_(ctx);
     if (!ctx || !elems_dev || !root) return fail(STARK_EARG, "null argument");
     return tree_build(ctx, (const fe*)elems_dev, n, root, tree_out);
+}
+
+// stark_merkle_commit_fe_dev without a retained tree and without any allocation: the tree is built
+// in the static device array and only the root leaves it.  Nothing is synchronised.
+extern "C" int32_t stark_merkle_root_fe_static_dev(stark_ctx* ctx, const uint64_t* elems_dev, size_t n,
+                                                   uint8_t* root_dev_out)
+{
+    CtxGuard guard_(ctx);
+    if (!ctx || !elems_dev || !root_dev_out) return fail(STARK_EARG, "null argument");
+    if (log2_exact(n) < 0) return fail(STARK_ENOTPOW2, "length must be power of two");
+    if (n > STATIC_TREE_MAX_LEAVES) return fail(STARK_ETOOLARGE, "more than 262144 leaves do not fit the static scratch");
+    if (!ctx->static_scratch) return fail(STARK_EHIP, "static scratch address unknown");
+    if (n == 1) {                                  // the single leaf digest is the root
+        HIP_TRY(launch_leaf_hash((const fe*)elems_dev, (digest*)root_dev_out, 1, ctx->stream));
+        return STARK_OK;
+    }
+    digest* tree = (digest*)ctx->static_scratch;   // every level is written in full before it is read: nothing to clear
+    HIP_TRY(launch_leaf_hash((const fe*)elems_dev, tree, n, ctx->stream));
+    HIP_TRY(launch_merkle_reduce(tree, n, ctx->stream, (digest*)root_dev_out));
+    return STARK_OK;
 }
 
 extern "C" int32_t stark_merkle_commit_fe(stark_ctx* ctx, const uint64_t* elems, size_t n, uint8_t root[32],

@@ -278,6 +278,11 @@ class Context:
         raw = bytes(roots)
         return [raw[32 * c:32 * (c + 1)] for c in range(n_cols)]
 
+    def merkle_root_fe_static_dev(self, dptr, n: int, root_dptr):
+        """Root of the n leaves at dptr into 32 bytes of device memory at root_dptr; the tree lives in the
+        library's static device array (n <= 2^18), nothing is allocated and nothing is synchronised."""
+        self._chk(self.lib.stark_merkle_root_fe_static_dev(self.h, _ptr(dptr), n, _ptr(root_dptr)))
+
     def merkle_subtree_roots_dev(self, dptr, chunk_len: int, n_chunks: int, roots_dptr, keep_forest: bool = False):
         """Subtree root of each of n_chunks aligned runs of chunk_len leaves, left in device memory.
         With keep_forest returns a Tree whose open(local leaf index) gives the siblings inside the subtree."""
