@@ -103,6 +103,57 @@ int32_t stark_vec_mul(stark_ctx* ctx, const uint64_t* a, const uint64_t* b, uint
 int32_t stark_vec_mul_dev(stark_ctx* ctx, const uint64_t* a_dev, const uint64_t* b_dev, uint64_t* out_dev,
                           size_t n);
 
+/* ---- polynomials as vectors ------------------------------------------------
+ * The algebra of Stark::prove (stark.rs:223-471) on polynomials too long for the
+ * reference's O(n^2) forms: a polynomial is a coefficient vector (lowest degree
+ * first) or its values on a coset, and every operation is a pass over device
+ * vectors between transforms.  None of these synchronises unless it says so.
+ *
+ * Polynomial::compose with the linear polynomial s*x (univariate_poly.rs:203-221,
+ * used as tp(omicron*x) at stark.rs:319-325): coefficient j of every column times s^j. */
+int32_t stark_poly_compose_linear_dev(stark_ctx* ctx, uint64_t* coeffs_dev, size_t n, size_t n_cols,
+                                      size_t col_stride, const uint64_t s[2]);
+/* The inverse of stark_coset_lde_batch_dev with n_coeffs = n_out = n: values on
+ * offset * omega_n^i -> the n coefficients, in place.  Polynomial::lagrange over
+ * that domain (univariate_poly.rs:127-177; with offset = 1, lagrange_ntt). */
+int32_t stark_coset_interpolate_batch_dev(stark_ctx* ctx, uint64_t* data_dev, size_t n, size_t n_cols,
+                                          size_t col_stride, const uint64_t offset[2]);
+/* out[i] = FieldElement::inverse(a[i]) (field.rs:67-93; 0 for 0, as there): the
+ * pointwise form of Polynomial Div (univariate_poly.rs:437-484) for a division
+ * known to be exact, on values that avoid the divisor's zeros.  May run in place. */
+int32_t stark_vec_inv_dev(stark_ctx* ctx, const uint64_t* a_dev, uint64_t* out_dev, size_t n);
+/* out[j] = sum_k weights[k] * srcs[k][j - shifts[k]], j < n_out (terms outside
+ * [0, lens[k]) count as zero; lens[k] + shifts[k] <= n_out; at most 16 terms):
+ * Polynomial Add, scalar Mul and Mul by x^shift in one pass, the weighted sum of
+ * stark.rs:385-404.  srcs, lens, shifts, weights (2 words each) are host arrays
+ * of device pointers / numbers. */
+int32_t stark_poly_lincomb_dev(stark_ctx* ctx, size_t n_terms, const uint64_t* const* srcs_dev, const size_t* lens,
+                               const size_t* shifts, const uint64_t* weights, uint64_t* out_dev, size_t n_out);
+/* MPolynomial::eval (multivariate_poly.rs:42-72) at n points at once, which on
+ * the values of the point polynomials is MPolynomial::eval_symbolic (:75-88,
+ * stark.rs:328-333): out[i] = sum_k coeffs[k] * prod_v cols[v][(i + rotations[v]) mod n] ^ exps[k*n_vars + v].
+ * cols_dev is a host array of n_vars <= 16 device pointers, rotations (may be
+ * NULL) turns a column of values on offset*omega^i into the values of the
+ * polynomial composed with omega^rot * x; coeffs (2 words each) and exps (one
+ * byte each) are host arrays.  If mul_dev is not NULL the result is multiplied
+ * by mul_dev[i] (a zeroifier's inverse values, stark.rs:336-341).  Synchronises. */
+int32_t stark_mpoly_eval_dev(stark_ctx* ctx, size_t n_vars, const uint64_t* const* cols_dev, const size_t* rotations,
+                             size_t n_terms, const uint64_t* coeffs, const uint8_t* exps, const uint64_t* mul_dev,
+                             uint64_t* out_dev, size_t n);
+/* Polynomial::degree (univariate_poly.rs:69-85) of n coefficients, lowest first:
+ * the largest index with a nonzero coefficient, 0 for the zero polynomial
+ * (*is_zero_out, if not NULL, tells the two apart).  Synchronises. */
+int32_t stark_poly_degree_dev(stark_ctx* ctx, const uint64_t* coeffs_dev, size_t n, size_t* degree_out,
+                              int32_t* is_zero_out);
+/* FieldElement::sample (field.rs:110-116) of n byte strings of `width` bytes
+ * lying back to back in device memory (the randomizer coefficients of
+ * stark.rs:345-351 from their raw random bytes).  String i lands at out[i], or
+ * at out[n-1-i] if reversed is non-zero: the reference fills Polynomial::coeffs,
+ * highest degree first (univariate_poly.rs:27), in drawing order, and the
+ * transforms here take coefficients lowest first. */
+int32_t stark_sample_bytes_dev(stark_ctx* ctx, const uint8_t* bytes_dev, size_t width, size_t n, int32_t reversed,
+                               uint64_t* out_dev);
+
 /* Twiddle step of a four-step transform of n_total points split over devices
  * (no counterpart in the single-threaded reference; the composition of the
  * steps equals NTT::forward/inverse, ntt.rs:25-40): the row-major block

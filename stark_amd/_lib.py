@@ -38,6 +38,14 @@ SIGNATURES = {
     "stark_ntt_batch_dev": (i32, [C.c_void_p, C.c_void_p, sz, sz, sz, i32]),
     "stark_coset_lde_batch": (i32, [C.c_void_p, C.c_void_p, sz, sz, sz, sz, u64p, C.c_void_p, sz]),
     "stark_coset_lde_batch_dev": (i32, [C.c_void_p, C.c_void_p, sz, sz, sz, sz, u64p, C.c_void_p, sz]),
+    "stark_poly_compose_linear_dev": (i32, [C.c_void_p, C.c_void_p, sz, sz, sz, u64p]),
+    "stark_coset_interpolate_batch_dev": (i32, [C.c_void_p, C.c_void_p, sz, sz, sz, u64p]),
+    "stark_vec_inv_dev": (i32, [C.c_void_p, C.c_void_p, C.c_void_p, sz]),
+    "stark_poly_lincomb_dev": (i32, [C.c_void_p, sz, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, sz]),
+    "stark_mpoly_eval_dev": (i32, [C.c_void_p, sz, C.c_void_p, C.c_void_p, sz, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, sz]),
+    "stark_poly_degree_dev": (i32, [C.c_void_p, C.c_void_p, sz, szp, C.POINTER(i32)]),
+    "stark_sample_bytes_dev": (i32, [C.c_void_p, C.c_void_p, sz, sz, i32, C.c_void_p]),
     "stark_fourstep_twiddle_dev": (i32, [C.c_void_p, C.c_void_p, sz, sz, sz, sz, i32]),
     "stark_vec_mul": (i32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, sz]),
     "stark_vec_mul_dev": (i32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, sz]),

@@ -1067,6 +1067,140 @@ extern "C" int32_t stark_vec_mul(stark_ctx* ctx, const uint64_t* a, const uint64
     return STARK_OK;
 }
 
+// ===========================================================================
+// pointwise polynomial work around the transforms
+// ===========================================================================
+extern "C" int32_t stark_poly_compose_linear_dev(stark_ctx* ctx, uint64_t* coeffs_dev, size_t n, size_t n_cols,
+                                                 size_t col_stride, const uint64_t s[2])
+{
+    CtxGuard guard_(ctx);
+    if (!ctx || !s || (n && n_cols && !coeffs_dev)) return fail(STARK_EARG, "null argument");
+    if (n == 0 || n_cols == 0) return STARK_OK;
+    if (n_cols > 1 && col_stride < n) return fail(STARK_ELENGTH, "column stride shorter than the column");
+    if (n_cols > 65535) return fail(STARK_ELENGTH, "too many columns in one call");
+    fe x{s[0], s[1]};
+    if (!is_canonical(x)) return fail(STARK_EARG, "scalar not reduced modulo p");
+    if (is_one(x)) return STARK_OK;
+    PowRef pt;
+    ST_TRY(get_pow_tables(ctx, x, n, false, &pt));
+    HIP_TRY(launch_compose_linear((fe*)coeffs_dev, n, n_cols, col_stride, (const fe*)pt->hi, (const fe*)pt->lo, ctx->stream));
+    return STARK_OK;
+}
+
+extern "C" int32_t stark_coset_interpolate_batch_dev(stark_ctx* ctx, uint64_t* data_dev, size_t n, size_t n_cols,
+                                                     size_t col_stride, const uint64_t offset[2])
+{
+    CtxGuard guard_(ctx);
+    if (!ctx || !offset || (n_cols && !data_dev)) return fail(STARK_EARG, "null argument");
+    fe off{offset[0], offset[1]};
+    if (!is_canonical(off) || fe_is_zero(off)) return fail(STARK_EARG, "offset must be a nonzero field element");
+    ST_TRY(stark_ntt_batch_dev(ctx, data_dev, n, n_cols, col_stride, 1));
+    fe inv = ctx->F.inverse(off);
+    const uint64_t inv_w[2] = {inv.lo, inv.hi};
+    return stark_poly_compose_linear_dev(ctx, data_dev, n, n_cols, col_stride, inv_w);
+}
+
+extern "C" int32_t stark_vec_inv_dev(stark_ctx* ctx, const uint64_t* a_dev, uint64_t* out_dev, size_t n)
+{
+    CtxGuard guard_(ctx);
+    if (!ctx || (n && (!a_dev || !out_dev))) return fail(STARK_EARG, "null argument");
+    HIP_TRY(launch_vec_inv((const fe*)a_dev, (fe*)out_dev, n, ctx->F.r2, ctx->F.one_m, ctx->stream));
+    return STARK_OK;
+}
+
+extern "C" int32_t stark_poly_lincomb_dev(stark_ctx* ctx, size_t n_terms, const uint64_t* const* srcs_dev,
+                                          const size_t* lens, const size_t* shifts, const uint64_t* weights,
+                                          uint64_t* out_dev, size_t n_out)
+{
+    CtxGuard guard_(ctx);
+    if (!ctx || (n_terms && (!srcs_dev || !lens || !shifts || !weights)) || (n_out && !out_dev))
+        return fail(STARK_EARG, "null argument");
+    if (n_terms > LINCOMB_MAX_TERMS) return fail(STARK_ELENGTH, "at most 16 terms in one call");
+    LincombArgs a{};
+    for (size_t k = 0; k < n_terms; k++) {
+        if (lens[k] && !srcs_dev[k]) return fail(STARK_EARG, "null term");
+        if (lens[k] + shifts[k] > n_out) return fail(STARK_ELENGTH, "term does not fit the output length");
+        fe w{weights[2 * k], weights[2 * k + 1]};
+        if (!is_canonical(w)) return fail(STARK_EARG, "scalar not reduced modulo p");
+        a.src[k] = (const fe*)srcs_dev[k];
+        a.len[k] = lens[k];
+        a.shift[k] = shifts[k];
+        a.weight_m[k] = ctx->F.to_mont(w);
+    }
+    a.out = (fe*)out_dev;
+    a.n_out = n_out;
+    a.n_terms = (uint32_t)n_terms;
+    HIP_TRY(launch_lincomb(a, ctx->stream));
+    return STARK_OK;
+}
+
+extern "C" int32_t stark_mpoly_eval_dev(stark_ctx* ctx, size_t n_vars, const uint64_t* const* cols_dev,
+                                        const size_t* rotations, size_t n_terms, const uint64_t* coeffs,
+                                        const uint8_t* exps, const uint64_t* mul_dev, uint64_t* out_dev, size_t n)
+{
+    CtxGuard guard_(ctx);
+    if (!ctx || !cols_dev || (n_terms && (!coeffs || !exps)) || (n && !out_dev)) return fail(STARK_EARG, "null argument");
+    if (n_vars == 0 || n_vars > MPOLY_MAX_VARS) return fail(STARK_ELENGTH, "between 1 and 16 variables");
+    if (n == 0) return STARK_OK;
+    MPolyArgs a{};
+    for (size_t v = 0; v < n_vars; v++) {
+        if (!cols_dev[v]) return fail(STARK_EARG, "null column");
+        a.cols[v] = (const fe*)cols_dev[v];
+        a.rot[v] = rotations ? rotations[v] % n : 0;
+    }
+    // term table: Montgomery-form coefficients, then 16 exponent bytes per term
+    const size_t coef_bytes = (n_terms ? n_terms : 1) * sizeof(fe);
+    std::vector<uint8_t> table(coef_bytes + (n_terms ? n_terms : 1) * MPOLY_MAX_VARS, 0);
+    for (size_t k = 0; k < n_terms; k++) {
+        fe c{coeffs[2 * k], coeffs[2 * k + 1]};
+        if (!is_canonical(c)) return fail(STARK_EARG, "scalar not reduced modulo p");
+        fe cm = ctx->F.to_mont(c);
+        memcpy(table.data() + k * sizeof(fe), &cm, sizeof(fe));
+        for (size_t v = 0; v < n_vars; v++) table[coef_bytes + k * MPOLY_MAX_VARS + v] = exps[k * n_vars + v];
+    }
+    DevBuf tb(ctx);
+    ST_TRY(tb.alloc(table.size()));
+    HIP_TRY(hipMemcpyAsync(tb.p, table.data(), table.size(), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));              // `table` is pageable host memory about to go away
+    a.coef_m = (const fe*)tb.p;
+    a.exps = (const uint8_t*)tb.p + coef_bytes;
+    a.mul = (const fe*)mul_dev;
+    a.out = (fe*)out_dev;
+    a.n = n;
+    a.n_vars = (uint32_t)n_vars;
+    a.n_terms = (uint32_t)n_terms;
+    a.r2 = ctx->F.r2;
+    HIP_TRY(launch_mpoly_eval(a, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));              // the table block returns to the cache on return
+    return STARK_OK;
+}
+
+extern "C" int32_t stark_poly_degree_dev(stark_ctx* ctx, const uint64_t* coeffs_dev, size_t n, size_t* degree_out,
+                                         int32_t* is_zero_out)
+{
+    CtxGuard guard_(ctx);
+    if (!ctx || (n && !coeffs_dev) || !degree_out) return fail(STARK_EARG, "null argument");
+    unsigned long long* mail = (unsigned long long*)((uint8_t*)ctx->pinned + 1024);      // host-mapped pinned word
+    *mail = 0;
+    HIP_TRY(launch_poly_degree((const fe*)coeffs_dev, n, mail, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    const unsigned long long r = *mail;
+    *degree_out = r ? (size_t)(r - 1) : 0;                   // univariate_poly.rs:69-85: the zero polynomial has degree 0
+    if (is_zero_out) *is_zero_out = r == 0;
+    return STARK_OK;
+}
+
+extern "C" int32_t stark_sample_bytes_dev(stark_ctx* ctx, const uint8_t* bytes_dev, size_t width, size_t n,
+                                          int32_t reversed, uint64_t* out_dev)
+{
+    CtxGuard guard_(ctx);
+    if (!ctx || (n && (!bytes_dev || !out_dev))) return fail(STARK_EARG, "null argument");
+    if (width == 0 || width > 0xFFFFFFFFull) return fail(STARK_ELENGTH, "byte strings must be 1 .. 2^32-1 bytes long");
+    HIP_TRY(launch_sample_bytes(bytes_dev, (uint32_t)width, (fe*)out_dev, n, ctx->F.to_mont(fe{256, 0}),
+                                reversed != 0, ctx->stream));
+    return STARK_OK;
+}
+
 extern "C" int32_t stark_fourstep_twiddle_dev(stark_ctx* ctx, uint64_t* data_dev, size_t n_total, size_t row_start,
                                               size_t n_rows, size_t n_cols, int32_t inverse)
 {

@@ -122,4 +122,42 @@ hipError_t launch_merkle_open_many(const digest* tree, size_t n, const uint64_t*
 
 hipError_t launch_gather_fe(const fe* src, const uint64_t* idx, fe* out, size_t count, hipStream_t s);
 
+// --- pointwise polynomial work (poly_kernels.hip) ------------------------------
+// data[c*stride + j] *= x^j, j < n; hi[e] = x^(256 e), lo[e] = x^e (Montgomery form)
+hipError_t launch_compose_linear(fe* data, uint64_t n, uint64_t n_cols, uint64_t stride, const fe* hi, const fe* lo,
+                                 hipStream_t s);
+// out[i] = 1 / a[i] (0 for 0); r2 = 2^256 mod p, one_m = 2^128 mod p
+hipError_t launch_vec_inv(const fe* a, fe* out, uint64_t n, fe r2, fe one_m, hipStream_t s);
+
+constexpr uint32_t LINCOMB_MAX_TERMS = 16;
+struct LincombArgs {
+    const fe* src[LINCOMB_MAX_TERMS];
+    uint64_t len[LINCOMB_MAX_TERMS];
+    uint64_t shift[LINCOMB_MAX_TERMS];
+    fe weight_m[LINCOMB_MAX_TERMS];      // Montgomery form
+    fe* out;
+    uint64_t n_out;
+    uint32_t n_terms;
+};
+hipError_t launch_lincomb(const LincombArgs& a, hipStream_t s);
+
+constexpr uint32_t MPOLY_MAX_VARS = 16;
+struct MPolyArgs {
+    const fe* cols[MPOLY_MAX_VARS];      // variable v at point i: cols[v][(i + rot[v]) mod n]
+    uint64_t rot[MPOLY_MAX_VARS];
+    const fe* coef_m;                    // n_terms coefficients, Montgomery form (device memory)
+    const uint8_t* exps;                 // n_terms x MPOLY_MAX_VARS exponents (device memory)
+    const fe* mul;                       // optional pointwise factor
+    fe* out;
+    uint64_t n;
+    uint32_t n_vars, n_terms;
+    fe r2;
+};
+hipError_t launch_mpoly_eval(const MPolyArgs& a, hipStream_t s);
+// *result_dev (zeroed by the caller) = 1 + largest index of a nonzero coefficient, 0 if none
+hipError_t launch_poly_degree(const fe* c, uint64_t n, unsigned long long* result_dev, hipStream_t s);
+// out[i] (out[n-1-i] if reversed) = big-endian integer of bytes[i*width .. (i+1)*width) modulo p
+hipError_t launch_sample_bytes(const uint8_t* bytes, uint32_t width, fe* out, uint64_t n, fe c256_m, bool reversed,
+                               hipStream_t s);
+
 }  // namespace starkk

@@ -1,0 +1,229 @@
+// Pointwise polynomial work of the prover around the transforms (gfx950): the
+// pieces of Stark::prove (src/modules/stark.rs:223-471) that the reference does
+// with symbolic O(n^2) algebra and that become passes over vectors once the
+// polynomials are held as values on a coset or as coefficient vectors.  All of
+// them are bound by HBM or by the 128-bit Montgomery product, none is a
+// contraction.  Field values in memory are canonical; constants travel in
+// Montgomery form (x * 2^128 mod p) so that one mont_mul gives a canonical
+// product.
+#include <hip/hip_runtime.h>
+
+#include "internal.hpp"
+
+namespace starkk {
+
+using namespace starkf;
+
+// coefficient j of every column times s^j (Polynomial::compose with the linear
+// polynomial s*x, univariate_poly.rs:203-221 as used at stark.rs:319-325);
+// hi[e] = s^(256 e), lo[e] = s^e in Montgomery form
+__global__ __launch_bounds__(256) void compose_linear_kernel(fe* __restrict__ data, uint64_t n, uint64_t stride,
+                                                             const fe* __restrict__ hi, const fe* __restrict__ lo)
+{
+    const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    fe* p = data + (uint64_t)blockIdx.y * stride + j;
+    fe w = hi[j >> 8];                                   // Montgomery form
+    const uint32_t el = (uint32_t)(j & 255);
+    if (el) w = mont_mul(w, lo[el]);
+    *p = mont_mul(*p, w);
+}
+
+hipError_t launch_compose_linear(fe* data, uint64_t n, uint64_t n_cols, uint64_t stride, const fe* hi, const fe* lo,
+                                 hipStream_t s)
+{
+    if (n == 0 || n_cols == 0) return hipSuccess;
+    if (n_cols > 65535) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(compose_linear_kernel, dim3((uint32_t)((n + 255) / 256), (uint32_t)n_cols), dim3(256), 0, s, data,
+                       n, stride, hi, lo);
+    return hipGetLastError();
+}
+
+// x^(p-2) for x in Montgomery form (FieldElement::inverse, field.rs:67-93, by Fermat).
+// p - 2 = 0xCB7F_FFFF_..._FFFF: the top byte 0xCB, then 0x7F, then 112 one bits.
+__device__ __forceinline__ fe mont_inverse(fe xm, fe one_m)
+{
+    // x^(2^k - 1) ladder for the long run of ones
+    fe r = one_m;
+    const u128 e = ((u128)0xCB7FFFFFFFFFFFFFull << 64) | 0xFFFFFFFFFFFFFFFFull;
+    for (int i = 127; i >= 0; i--) {
+        r = mont_mul(r, r);
+        if ((e >> i) & 1) r = mont_mul(r, xm);
+    }
+    return r;
+}
+
+// out[i] = 1 / a[i], 0 for 0 (the reference's inverse(0) is 0).  Each thread
+// inverts INV_K elements with one field inversion (Montgomery's trick): prefix
+// products, one Fermat power, and two multiplications per element on the way
+// back.  Element k of thread t in block b is b*INV_K*256 + k*256 + t, so every
+// access of a wave is contiguous.
+constexpr int INV_K = 8;
+__global__ __launch_bounds__(256) void vec_inv_kernel(const fe* __restrict__ a, fe* __restrict__ out, uint64_t n,
+                                                      fe r2, fe one_m)
+{
+    const uint64_t base = (uint64_t)blockIdx.x * (INV_K * 256) + threadIdx.x;
+    fe x[INV_K], pre[INV_K];
+    fe acc = one_m;
+#pragma unroll
+    for (int k = 0; k < INV_K; k++) {
+        const uint64_t i = base + (uint64_t)k * 256;
+        fe v = fe_zero();
+        if (i < n) v = a[i];
+        x[k] = fe_is_zero(v) ? one_m : mont_mul(v, r2);      // Montgomery form; zeros (and the tail) ride along as 1
+        pre[k] = acc;
+        acc = mont_mul(acc, x[k]);
+        if (fe_is_zero(v)) x[k] = fe_zero();                 // remembered as a zero for the way back
+    }
+    fe inv = mont_inverse(acc, one_m);
+#pragma unroll
+    for (int k = INV_K - 1; k >= 0; k--) {
+        const uint64_t i = base + (uint64_t)k * 256;
+        const bool zero = fe_is_zero(x[k]);
+        const fe xi = zero ? one_m : x[k];
+        const fe r = mont_mul(inv, pre[k]);                  // (1/x_k) in Montgomery form
+        inv = mont_mul(inv, xi);
+        if (i < n) out[i] = zero ? fe_zero() : mont_mul(r, fe{1, 0});
+    }
+}
+
+hipError_t launch_vec_inv(const fe* a, fe* out, uint64_t n, fe r2, fe one_m, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    const uint64_t per_block = (uint64_t)INV_K * 256;
+    hipLaunchKernelGGL(vec_inv_kernel, dim3((uint32_t)((n + per_block - 1) / per_block)), dim3(256), 0, s, a, out, n, r2,
+                       one_m);
+    return hipGetLastError();
+}
+
+// out[j] = sum_k w_k * src_k[j - shift_k]: a weighted sum of polynomials times
+// powers of x in coefficient form (stark.rs:385-404: terms, shifts by
+// x^(max_degree - bound), weights).  Weights in Montgomery form.
+__global__ __launch_bounds__(256) void lincomb_kernel(LincombArgs a)
+{
+    const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= a.n_out) return;
+    fe acc = fe_zero();
+    for (uint32_t k = 0; k < a.n_terms; k++) {
+        const uint64_t sh = a.shift[k];
+        if (j >= sh && j - sh < a.len[k]) acc = fe_add(acc, mont_mul(a.src[k][j - sh], a.weight_m[k]));
+    }
+    a.out[j] = acc;
+}
+
+hipError_t launch_lincomb(const LincombArgs& a, hipStream_t s)
+{
+    if (a.n_out == 0) return hipSuccess;
+    if (a.n_terms > LINCOMB_MAX_TERMS) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(lincomb_kernel, dim3((uint32_t)((a.n_out + 255) / 256)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// MPolynomial::eval (multivariate_poly.rs:42-72) at n points at once: the
+// coordinates of point i are cols[v][(i + rot[v]) mod n].  A thread keeps its
+// point's coordinates in LDS in Montgomery form (the term table is indexed at
+// run time, which registers cannot be) and walks the term table, which is the
+// same for every thread and is read through the scalar path.  If `mul` is
+// given the value is multiplied by mul[i] on the way out (the division by a
+// zeroifier whose inverse values are at hand, stark.rs:336-341).
+constexpr int MPOLY_THREADS = 128;
+__global__ __launch_bounds__(MPOLY_THREADS) void mpoly_eval_kernel(MPolyArgs a)
+{
+    __shared__ fe pt[MPOLY_MAX_VARS][MPOLY_THREADS];
+    const uint32_t t = threadIdx.x;
+    const uint64_t i = (uint64_t)blockIdx.x * MPOLY_THREADS + t;
+    if (i >= a.n) return;
+    for (uint32_t v = 0; v < a.n_vars; v++) {
+        uint64_t idx = i + a.rot[v];
+        if (idx >= a.n) idx -= a.n;
+        pt[v][t] = mont_mul(a.cols[v][idx], a.r2);
+    }
+    fe acc = fe_zero();
+    for (uint32_t k = 0; k < a.n_terms; k++) {
+        fe prod = a.coef_m[k];
+        const uint8_t* __restrict__ ex = a.exps + (size_t)k * MPOLY_MAX_VARS;
+        for (uint32_t v = 0; v < a.n_vars; v++) {
+            uint32_t e = ex[v];
+            if (e == 0) continue;
+            fe b = pt[v][t];
+            // left-to-right over the bits of e: e is small (the AIR's degree)
+            fe p = b;
+            int top = 31 - __builtin_clz(e);
+            for (int bit = top - 1; bit >= 0; bit--) {
+                p = mont_mul(p, p);
+                if ((e >> bit) & 1) p = mont_mul(p, b);
+            }
+            prod = mont_mul(prod, p);
+        }
+        acc = fe_add(acc, prod);
+    }
+    fe o = mont_mul(acc, fe{1, 0});                          // out of Montgomery form
+    if (a.mul) o = mont_mul(mont_mul(o, a.mul[i]), a.r2);
+    a.out[i] = o;
+}
+
+hipError_t launch_mpoly_eval(const MPolyArgs& a, hipStream_t s)
+{
+    if (a.n == 0) return hipSuccess;
+    if (a.n_vars > MPOLY_MAX_VARS) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(mpoly_eval_kernel, dim3((uint32_t)((a.n + MPOLY_THREADS - 1) / MPOLY_THREADS)), dim3(MPOLY_THREADS),
+                       0, s, a);
+    return hipGetLastError();
+}
+
+// Polynomial::degree (univariate_poly.rs:69-85) of a coefficient vector, lowest
+// degree first: *result = 1 + the largest index holding a nonzero coefficient,
+// 0 when there is none.  *result must be zero before the launch.
+__global__ __launch_bounds__(256) void poly_degree_kernel(const fe* __restrict__ c, uint64_t n,
+                                                          unsigned long long* __restrict__ result)
+{
+    uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint64_t step = (uint64_t)gridDim.x * 256;
+    unsigned long long best = 0;
+    for (; i < n; i += step)
+        if (!fe_is_zero(c[i])) best = i + 1;
+    // one atomic per wave: the largest candidate of the 64 lanes
+    for (int off = 32; off >= 1; off >>= 1) {
+        const unsigned long long o = __shfl_xor(best, off);
+        best = o > best ? o : best;
+    }
+    if ((threadIdx.x & 63) == 0 && best) atomicMax(result, best);
+}
+
+hipError_t launch_poly_degree(const fe* c, uint64_t n, unsigned long long* result_dev, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    uint64_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(poly_degree_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, c, n, result_dev);
+    return hipGetLastError();
+}
+
+// FieldElement::sample (field.rs:110-116) of n byte strings of `width` bytes each:
+// the big-endian integer of the bytes modulo p, accumulated byte by byte as the
+// reference does.  The randomizer coefficients of stark.rs:345-351 from their
+// raw random bytes.  c256_m = 256 in Montgomery form.  With `reversed` string i
+// lands at out[n-1-i]: the reference fills Polynomial::coeffs, which is highest
+// degree first (univariate_poly.rs:27), in drawing order.
+__global__ __launch_bounds__(256) void sample_bytes_kernel(const uint8_t* __restrict__ bytes, uint32_t width,
+                                                           fe* __restrict__ out, uint64_t n, fe c256_m, int reversed)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t* p = bytes + i * width;
+    fe acc = fe_zero();
+    for (uint32_t k = 0; k < width; k++) acc = fe_add(mont_mul(acc, c256_m), fe{p[k], 0});
+    out[reversed ? n - 1 - i : i] = acc;
+}
+
+hipError_t launch_sample_bytes(const uint8_t* bytes, uint32_t width, fe* out, uint64_t n, fe c256_m, bool reversed,
+                               hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    if (width == 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(sample_bytes_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, bytes, width, out, n,
+                       c256_m, reversed ? 1 : 0);
+    return hipGetLastError();
+}
+
+}  // namespace starkk

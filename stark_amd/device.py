@@ -246,6 +246,58 @@ class Context:
         self._chk(self.lib.stark_fourstep_twiddle_dev(self.h, _ptr(dptr), n_total, row_start, n_rows, n_cols,
                                                       int(inverse)))
 
+    # ---- polynomials as device vectors --------------------------------------
+    def vec_mul_dev(self, a_ptr, b_ptr, out_ptr, n: int):
+        self._chk(self.lib.stark_vec_mul_dev(self.h, _ptr(a_ptr), _ptr(b_ptr), _ptr(out_ptr), n))
+
+    def vec_inv_dev(self, a_ptr, out_ptr, n: int):
+        """out[i] = 1 / a[i] (0 for 0)."""
+        self._chk(self.lib.stark_vec_inv_dev(self.h, _ptr(a_ptr), _ptr(out_ptr), n))
+
+    def poly_compose_linear_dev(self, coeffs_ptr, n: int, s: int, n_cols: int = 1, col_stride: Optional[int] = None):
+        """Coefficient j (lowest first) of every column times s^j."""
+        self._chk(self.lib.stark_poly_compose_linear_dev(self.h, _ptr(coeffs_ptr), n, n_cols, col_stride or n, _fe(s)))
+
+    def coset_interpolate_batch_dev(self, data_ptr, n: int, offset: int, n_cols: int = 1,
+                                    col_stride: Optional[int] = None):
+        """Values on offset * omega_n^i -> the n coefficients, in place."""
+        self._chk(self.lib.stark_coset_interpolate_batch_dev(self.h, _ptr(data_ptr), n, n_cols, col_stride or n,
+                                                             _fe(offset)))
+
+    def poly_lincomb_dev(self, terms, out_ptr, n_out: int):
+        """terms: (device pointer, length, shift, weight) each; out[j] = sum weight * src[j - shift]."""
+        k = len(terms)
+        srcs = (C.c_void_p * max(k, 1))(*[_ptr(t[0]) for t in terms])
+        lens = (C.c_size_t * max(k, 1))(*[t[1] for t in terms])
+        shifts = (C.c_size_t * max(k, 1))(*[t[2] for t in terms])
+        w = (C.c_uint64 * max(2 * k, 2))()
+        for i, t in enumerate(terms):
+            w[2 * i], w[2 * i + 1] = t[3] & 0xFFFFFFFFFFFFFFFF, t[3] >> 64
+        self._chk(self.lib.stark_poly_lincomb_dev(self.h, k, srcs, lens, shifts, w, _ptr(out_ptr), n_out))
+
+    def mpoly_eval_dev(self, cols, rotations, terms, out_ptr, n: int, mul_ptr=None):
+        """terms: (coefficient, exponent tuple over the columns) each; out[i] = sum c * prod cols[v][(i + rot[v]) % n]^e."""
+        nv, k = len(cols), len(terms)
+        ptrs = (C.c_void_p * nv)(*[_ptr(c) for c in cols])
+        rot = (C.c_size_t * nv)(*(rotations or [0] * nv))
+        w = (C.c_uint64 * max(2 * k, 2))()
+        ex = (C.c_uint8 * max(k * nv, 1))()
+        for i, (c, e) in enumerate(terms):
+            w[2 * i], w[2 * i + 1] = c & 0xFFFFFFFFFFFFFFFF, c >> 64
+            for v in range(nv):
+                ex[i * nv + v] = e[v] if v < len(e) else 0
+        self._chk(self.lib.stark_mpoly_eval_dev(self.h, nv, ptrs, rot, k, w, ex,
+                                                None if mul_ptr is None else _ptr(mul_ptr), _ptr(out_ptr), n))
+
+    def poly_degree_dev(self, coeffs_ptr, n: int):
+        """(degree, is_zero) of n coefficients, lowest first."""
+        d, z = C.c_size_t(0), C.c_int32(0)
+        self._chk(self.lib.stark_poly_degree_dev(self.h, _ptr(coeffs_ptr), n, C.byref(d), C.byref(z)))
+        return d.value, bool(z.value)
+
+    def sample_bytes_dev(self, bytes_ptr, width: int, n: int, out_ptr, reversed_: bool = False):
+        self._chk(self.lib.stark_sample_bytes_dev(self.h, _ptr(bytes_ptr), width, n, int(reversed_), _ptr(out_ptr)))
+
     def vec_mul(self, a, b) -> np.ndarray:
         a, b = _as_fe_array(a), _as_fe_array(b)
         assert a.shape == b.shape

@@ -8,6 +8,7 @@
 
 #include "stark_host.hpp"
 #include "stark_prover.hpp"
+#include "stark_scaled.hpp"
 
 using namespace stark;
 
@@ -414,6 +415,99 @@ int sh_stark_rescue_verify(const uint64_t* output, size_t expansion, size_t ncol
                             rp.boundary_constraints(ld(output)))
                    ? 1
                    : 0;)
+}
+
+// ---- the long-trace prover (stark_scaled.hpp) ----------------------------------
+// A Rescue-Prime chain of `rows` rows with its trace, AIR, constant columns and the ScaledStark made for it.
+struct ChainJob {
+    RescueChain chain;
+    ScaledStark stark;
+    std::vector<std::vector<FieldElement>> trace, constants;
+    std::vector<MPolynomial> air;
+    ChainJob(const FieldElement& input, size_t rows, size_t expansion, size_t ncol, size_t security)
+        : chain(rows), stark(expansion, ncol, security, chain.rp.m, rows), trace(chain.trace(input)),
+          constants(chain.constant_columns()), air(chain.air())
+    {
+    }
+};
+
+void* sh_chain_new(const uint64_t* input, size_t rows, size_t expansion, size_t ncol, size_t security)
+{
+    try {
+        return new ChainJob(ld(input), rows, expansion, ncol, security);
+    } catch (const std::exception& e) {
+        g_panic = e.what();
+        return nullptr;
+    }
+}
+void sh_chain_free(void* h) { delete (ChainJob*)h; }
+int sh_chain_output(void* h, uint64_t* out)
+{
+    GUARD(st(out, ((ChainJob*)h)->trace.back()[0]); return 0;)
+}
+// random bytes one proof draws: 17 per randomizer value and per randomizer coefficient
+size_t sh_chain_random_bytes(void* h)
+{
+    ChainJob* j = (ChainJob*)h;
+    return 17 * (j->stark.num_randomizers * j->stark.num_registers + j->stark.max_degree(j->air) + 1);
+}
+// adds 1 to one trace value: the trace no longer follows the round function there
+void sh_chain_corrupt(void* h, size_t row, size_t reg)
+{
+    ChainJob* j = (ChainJob*)h;
+    j->trace.at(row).at(reg) = j->trace[row][reg] + FieldElement::one();
+}
+size_t sh_chain_fri_domain_length(void* h) { return ((ChainJob*)h)->stark.fri_domain_length; }
+// returns the random bytes used; timings (may be NULL) receives host, interpolate, quotients, lde, merkle, fri,
+// openings, total in milliseconds
+int sh_chain_prove(void* h, const uint8_t* random, size_t n_random, uint8_t* proof_out, size_t* proof_len,
+                   double* timings)
+{
+    GUARD(
+        ChainJob* j = (ChainJob*)h;
+        size_t used = 0;
+        RandomSource rng = [&](uint8_t* dst, size_t n) {
+            if (used + n > n_random) throw Panic("random bytes exhausted");
+            std::memcpy(dst, random + used, n);
+            used += n;
+        };
+        ProveTimings tm;
+        std::vector<uint8_t> proof = j->stark.prove(j->trace, j->air, j->constants,
+                                                    j->chain.boundary_constraints(j->trace.back()[0]), rng, &tm);
+        if (proof_out) {
+            if (*proof_len < proof.size()) throw Panic("proof buffer too small");
+            std::memcpy(proof_out, proof.data(), proof.size());
+        }
+        *proof_len = proof.size();
+        if (timings) {
+            const double t[8] = {tm.host, tm.interpolate, tm.quotients, tm.lde, tm.merkle, tm.fri, tm.openings, tm.total};
+            std::memcpy(timings, t, sizeof t);
+        }
+        return (int)std::min<size_t>(used, 0x7fffffff);)
+}
+// 1 accept / 0 reject / -1 panic
+int sh_chain_verify(void* h, const uint64_t* output, const uint8_t* proof, size_t proof_len)
+{
+    GUARD(
+        ChainJob* j = (ChainJob*)h;
+        return j->stark.verify(std::vector<uint8_t>(proof, proof + proof_len), j->air, j->constants,
+                               j->chain.boundary_constraints(ld(output)))
+                   ? 1
+                   : 0;)
+}
+// Polynomial::lagrange over (q^i, ys[c][i]), i < m, cols columns back to back, through GeometricDomain; also
+// the zeroifier of the first m points (m + 1 coefficients, lowest first) if zeroifier_out is not NULL
+int sh_geometric_interpolate(const uint64_t* q, size_t n_table, const uint64_t* ys, size_t m, size_t cols,
+                             uint64_t* coeffs_out, uint64_t* zeroifier_out)
+{
+    GUARD(
+        GeometricDomain geo(ld(q), n_table);
+        DeviceVector in(std::max<size_t>(1, m * cols)), out(std::max<size_t>(1, m * cols));
+        in.upload(ldv(ys, m * cols));
+        geo.interpolate(in.words(), m, cols, m, out.words(), m);
+        stv(coeffs_out, out.download(0, m * cols));
+        if (zeroifier_out) stv(zeroifier_out, geo.zeroifier(m));
+        return 0;)
 }
 
 }  // extern "C"
