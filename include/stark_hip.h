@@ -162,6 +162,21 @@ int32_t stark_sample_bytes_dev(stark_ctx* ctx, const uint8_t* bytes_dev, size_t 
 int32_t stark_fourstep_twiddle_dev(stark_ctx* ctx, uint64_t* data_dev, size_t n_total, size_t row_start,
                                    size_t n_rows, size_t n_cols, int32_t inverse);
 
+/* The two local steps around the all-to-all of a four-step transform (same
+ * contract: the composition equals NTT::forward/inverse, ntt.rs:25-40).  A device
+ * holds n_rows rows of a matrix with n_cols columns, row-major; pack writes what
+ * it sends: dst[d][c][r] = src[r][d*cpw + c], cpw = n_cols / world, so that the
+ * block for device d is the transpose of that device's share of the columns.  If
+ * twiddle is non-zero, element (r, col) is multiplied on the way by
+ * w^((row_start + r) * col), w = primitive_nth_root(n_total) (its inverse for
+ * twiddle < 0): stark_fourstep_twiddle_dev without a pass of its own.  unpack
+ * puts the blocks a device received, src[s][b][a] (s < world sources, b < n_rows,
+ * a < run), side by side as rows dst[b][s][a].  Neither runs in place. */
+int32_t stark_fourstep_pack_dev(stark_ctx* ctx, const uint64_t* src_dev, size_t n_rows, size_t n_cols, size_t world,
+                                size_t n_total, size_t row_start, int32_t twiddle, uint64_t* dst_dev);
+int32_t stark_fourstep_unpack_dev(stark_ctx* ctx, const uint64_t* src_dev, size_t world, size_t n_rows, size_t run,
+                                  uint64_t* dst_dev);
+
 /* ---- Merkle ------------------------------------------------------------------
  * Merkle::commit (merkle.rs:38-51) over the leaves
  * bincode::serialize(&FieldElement) of n field elements (fri.rs:119,

@@ -47,6 +47,8 @@ SIGNATURES = {
     "stark_poly_degree_dev": (i32, [C.c_void_p, C.c_void_p, sz, szp, C.POINTER(i32)]),
     "stark_sample_bytes_dev": (i32, [C.c_void_p, C.c_void_p, sz, sz, i32, C.c_void_p]),
     "stark_fourstep_twiddle_dev": (i32, [C.c_void_p, C.c_void_p, sz, sz, sz, sz, i32]),
+    "stark_fourstep_pack_dev": (i32, [C.c_void_p, C.c_void_p, sz, sz, sz, sz, sz, i32, C.c_void_p]),
+    "stark_fourstep_unpack_dev": (i32, [C.c_void_p, C.c_void_p, sz, sz, sz, C.c_void_p]),
     "stark_vec_mul": (i32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, sz]),
     "stark_vec_mul_dev": (i32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, sz]),
     "stark_merkle_commit_fe": (i32, [C.c_void_p, C.c_void_p, sz, u8p, voidpp]),

@@ -1221,6 +1221,41 @@ extern "C" int32_t stark_fourstep_twiddle_dev(stark_ctx* ctx, uint64_t* data_dev
     return STARK_OK;
 }
 
+extern "C" int32_t stark_fourstep_pack_dev(stark_ctx* ctx, const uint64_t* src_dev, size_t n_rows, size_t n_cols,
+                                           size_t world, size_t n_total, size_t row_start, int32_t twiddle,
+                                           uint64_t* dst_dev)
+{
+    CtxGuard guard_(ctx);
+    if (!ctx || (n_rows * n_cols && (!src_dev || !dst_dev))) return fail(STARK_EARG, "null argument");
+    if (world == 0 || n_cols % world) return fail(STARK_ELENGTH, "the columns do not divide among the devices");
+    if (src_dev == dst_dev && n_rows * n_cols) return fail(STARK_EARG, "pack cannot run in place");
+    if (n_rows == 0 || n_cols == 0) return STARK_OK;
+    PowRef pt;
+    if (twiddle) {
+        int log_n;
+        ST_TRY(check_ntt_size(n_total, &log_n));
+        if (n_cols > 1 && (row_start + n_rows - 1) * (n_cols - 1) >= n_total)
+            return fail(STARK_ELENGTH, "twiddle block exceeds the transform size");
+        fe w = ctx->F.primitive_nth_root((unsigned)log_n);
+        if (twiddle < 0) w = ctx->F.inverse(w);
+        ST_TRY(get_pow_tables(ctx, w, n_total, false, &pt));
+    }
+    HIP_TRY(launch_fourstep_pack((const fe*)src_dev, (fe*)dst_dev, n_rows, n_cols, world, row_start,
+                                 pt ? (const fe*)pt->hi : nullptr, pt ? (const fe*)pt->lo : nullptr, ctx->stream));
+    return STARK_OK;
+}
+
+extern "C" int32_t stark_fourstep_unpack_dev(stark_ctx* ctx, const uint64_t* src_dev, size_t world, size_t n_rows,
+                                             size_t run, uint64_t* dst_dev)
+{
+    CtxGuard guard_(ctx);
+    const size_t total = world * n_rows * run;
+    if (!ctx || (total && (!src_dev || !dst_dev))) return fail(STARK_EARG, "null argument");
+    if (src_dev == dst_dev && total) return fail(STARK_EARG, "unpack cannot run in place");
+    HIP_TRY(launch_fourstep_unpack((const fe*)src_dev, (fe*)dst_dev, world, n_rows, run, ctx->stream));
+    return STARK_OK;
+}
+
 // ===========================================================================
 // Merkle
 // ===========================================================================

@@ -74,6 +74,12 @@ hipError_t launch_ntt_small(const SmallArgs& a, uint32_t n_batch, hipStream_t s)
 hipError_t launch_fourstep_twiddle(fe* data, uint64_t row_start, uint64_t n_rows, uint64_t n_cols, const fe* hi,
                                    const fe* lo, hipStream_t s);
 
+// dst[d][c][r] = src[r][d*cpw + c] (times w^((row_start + r)(d*cpw + c)) when hi/lo are given), cpw = n_cols/world
+hipError_t launch_fourstep_pack(const fe* src, fe* dst, uint64_t n_rows, uint64_t n_cols, uint64_t world,
+                                uint64_t row_start, const fe* hi, const fe* lo, hipStream_t s);
+// dst[b][s][a] = src[s][b][a], s < world, b < n_rows, a < run
+hipError_t launch_fourstep_unpack(const fe* src, fe* dst, uint64_t world, uint64_t n_rows, uint64_t run, hipStream_t s);
+
 hipError_t launch_vec_mul(const fe* a, const fe* b, fe* out, size_t n, fe r2, hipStream_t s);
 
 // --- Merkle / FRI -----------------------------------------------------------

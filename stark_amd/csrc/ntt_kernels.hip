@@ -596,6 +596,88 @@ hipError_t launch_fourstep_twiddle(fe* data, uint64_t row_start, uint64_t n_rows
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------
+// The exchanges of a four-step transform split over devices.  A device holds
+// n_rows rows of an (all rows) x n_cols matrix; the all-to-all that transposes
+// the matrix sends the columns [d * cpw, (d + 1) * cpw) of those rows to device
+// d (cpw = n_cols / world), and what device d needs from them is their
+// transpose.  pack writes the send buffer [d][column within d's share][row]
+// through 32 x 32 tiles in LDS (both the reads and the writes are runs of 512
+// contiguous bytes) and, on the exchange that follows the first set of local
+// transforms, multiplies element (row, column) by w^((row_start + row) * column)
+// on the way, so the twiddle step costs no pass of its own.  unpack puts the
+// received blocks [source][row][run] side by side as rows [row][source][run].
+// ---------------------------------------------------------------------------
+constexpr int XT = 32;
+template <bool TWIDDLE>
+__global__ __launch_bounds__(256) void fourstep_pack_kernel(const fe* __restrict__ src, fe* __restrict__ dst,
+                                                            uint64_t n_rows, uint64_t n_cols, uint64_t cpw,
+                                                            uint64_t row_start, const fe* __restrict__ hi,
+                                                            const fe* __restrict__ lo)
+{
+    __shared__ fe tile[XT][XT + 1];
+    const uint32_t tx = threadIdx.x & (XT - 1), ty = threadIdx.x / XT;      // ty < 8
+    const uint64_t d = blockIdx.z;
+    const uint64_t c0 = (uint64_t)blockIdx.x * XT, r0 = (uint64_t)blockIdx.y * XT;
+#pragma unroll
+    for (int k = 0; k < XT / 8; k++) {
+        const uint64_t r = r0 + ty + 8 * k, c = c0 + tx;
+        if (r < n_rows && c < cpw) {
+            const uint64_t cg = d * cpw + c;
+            fe v = src[r * n_cols + cg];
+            if constexpr (TWIDDLE) {
+                const uint64_t E = (row_start + r) * cg;
+                fe w = hi[E >> 8];
+                const uint32_t el = (uint32_t)(E & 255);
+                if (el) w = mont_mul(w, lo[el]);
+                v = mont_mul(v, w);
+            }
+            tile[ty + 8 * k][tx] = v;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < XT / 8; k++) {
+        const uint64_t c = c0 + ty + 8 * k, r = r0 + tx;
+        if (r < n_rows && c < cpw) dst[(d * cpw + c) * n_rows + r] = tile[tx][ty + 8 * k];
+    }
+}
+
+hipError_t launch_fourstep_pack(const fe* src, fe* dst, uint64_t n_rows, uint64_t n_cols, uint64_t world,
+                                uint64_t row_start, const fe* hi, const fe* lo, hipStream_t s)
+{
+    if (n_rows == 0 || n_cols == 0) return hipSuccess;
+    const uint64_t cpw = n_cols / world;
+    const uint64_t gx = (cpw + XT - 1) / XT, gy = (n_rows + XT - 1) / XT;
+    if (gx > 0x7fffffffull || gy > 65535 || world > 65535) return hipErrorInvalidValue;
+    dim3 grid((uint32_t)gx, (uint32_t)gy, (uint32_t)world);
+    if (hi) hipLaunchKernelGGL(fourstep_pack_kernel<true>, grid, dim3(256), 0, s, src, dst, n_rows, n_cols, cpw, row_start, hi, lo);
+    else hipLaunchKernelGGL(fourstep_pack_kernel<false>, grid, dim3(256), 0, s, src, dst, n_rows, n_cols, cpw, row_start, hi, lo);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void fourstep_unpack_kernel(const fe* __restrict__ src, fe* __restrict__ dst,
+                                                              uint64_t world, uint64_t n_rows, uint64_t run)
+{
+    const uint64_t total = world * n_rows * run;
+    uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint64_t step = (uint64_t)gridDim.x * 256;
+    for (; i < total; i += step) {
+        const uint64_t a = i % run, q = i / run, sidx = q % world, b = q / world;
+        dst[i] = src[(sidx * n_rows + b) * run + a];
+    }
+}
+
+hipError_t launch_fourstep_unpack(const fe* src, fe* dst, uint64_t world, uint64_t n_rows, uint64_t run, hipStream_t s)
+{
+    const uint64_t total = world * n_rows * run;
+    if (total == 0) return hipSuccess;
+    uint64_t blocks = (total + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(fourstep_unpack_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, src, dst, world, n_rows, run);
+    return hipGetLastError();
+}
+
 hipError_t launch_vec_mul(const fe* a, const fe* b, fe* out, size_t n, fe r2, hipStream_t s)
 {
     if (n == 0) return hipSuccess;

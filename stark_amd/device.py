@@ -246,6 +246,16 @@ class Context:
         self._chk(self.lib.stark_fourstep_twiddle_dev(self.h, _ptr(dptr), n_total, row_start, n_rows, n_cols,
                                                       int(inverse)))
 
+    def fourstep_pack_dev(self, src_ptr, n_rows: int, n_cols: int, world: int, dst_ptr, n_total: int = 0,
+                          row_start: int = 0, twiddle: int = 0):
+        """dst[d][c][r] = src[r][d*(n_cols/world) + c], times w^((row_start + r) * column) if twiddle (+1 / -1)."""
+        self._chk(self.lib.stark_fourstep_pack_dev(self.h, _ptr(src_ptr), n_rows, n_cols, world, n_total, row_start,
+                                                   twiddle, _ptr(dst_ptr)))
+
+    def fourstep_unpack_dev(self, src_ptr, world: int, n_rows: int, run: int, dst_ptr):
+        """dst[b][s][a] = src[s][b][a]."""
+        self._chk(self.lib.stark_fourstep_unpack_dev(self.h, _ptr(src_ptr), world, n_rows, run, _ptr(dst_ptr)))
+
     # ---- polynomials as device vectors --------------------------------------
     def vec_mul_dev(self, a_ptr, b_ptr, out_ptr, n: int):
         self._chk(self.lib.stark_vec_mul_dev(self.h, _ptr(a_ptr), _ptr(b_ptr), _ptr(out_ptr), n))

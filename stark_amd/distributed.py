@@ -59,6 +59,26 @@ class HipEngine:
         rows, cols, _ = t.shape
         self.ctx.fourstep_twiddle_dev(t, n_total, row_start, rows, cols, inverse=inverse)
 
+    def pack(self, t: torch.Tensor, world: int, twiddle=None) -> torch.Tensor:
+        """Send buffer [dest][column within dest's share][row] of this rank's rows t (rows, cols, 2), with the
+        four-step twiddle (n_total, row_start, inverse) applied on the way if given: one HIP kernel."""
+        self._bind(t)
+        rows, cols, _ = t.shape
+        send = torch.empty((world, cols // world, rows, 2), dtype=t.dtype, device=t.device)
+        if twiddle is None:
+            self.ctx.fourstep_pack_dev(t, rows, cols, world, send)
+        else:
+            n_total, row_start, inverse = twiddle
+            self.ctx.fourstep_pack_dev(t, rows, cols, world, send, n_total, row_start, -1 if inverse else 1)
+        return send
+
+    def unpack(self, recv: torch.Tensor, world: int, rows: int, run: int) -> torch.Tensor:
+        """Received blocks [source][row][run] -> rows (rows, world * run, 2): one HIP kernel."""
+        self._bind(recv)
+        out = torch.empty((rows, world * run, 2), dtype=recv.dtype, device=recv.device)
+        self.ctx.fourstep_unpack_dev(recv, world, rows, run, out)
+        return out
+
     def coset_lde(self, coeffs: torch.Tensor, n_out: int, offset: int) -> torch.Tensor:
         self._bind(coeffs)
         cols, n_coeffs, _ = coeffs.shape
@@ -164,16 +184,39 @@ def lde_commit_columns(engine, coeffs_local: torch.Tensor, n_cols: int, n_out: i
 # ---------------------------------------------------------------------------
 # four-step NTT across ranks
 # ---------------------------------------------------------------------------
-def _a2a_transpose(t: torch.Tensor, group) -> torch.Tensor:
+def _all_to_all(send: torch.Tensor, group) -> torch.Tensor:
+    """Equal-split all-to-all of a flat send buffer [dest][...]; through the host when the group's backend
+    cannot take device tensors (gloo in tests)."""
+    if dist.get_backend(group) == "nccl" or not send.is_cuda:
+        recv = torch.empty_like(send)
+        dist.all_to_all_single(recv.view(-1), send.view(-1), group=group)
+        return recv
+    host = send.cpu()
+    out = torch.empty_like(host)
+    dist.all_to_all_single(out.view(-1), host.view(-1), group=group)
+    return out.to(send.device)
+
+
+def _a2a_transpose(t: torch.Tensor, group, engine=None, twiddle=None) -> torch.Tensor:
     """t is this rank's rows of a (A x B) matrix, shape (A/G, B, 2).  Returns
     this rank's rows of the transposed (B x A) matrix, shape (B/G, A, 2).
-    One all-to-all; each rank sends (A/G)*(B/G) elements to every peer."""
+    One all-to-all; each rank sends (A/G)*(B/G) elements to every peer.
+    twiddle = (n_total, row_start, inverse): element (row, column) is multiplied by
+    w_n^((row_start + row) * column) before it travels.  An engine with pack/unpack
+    (the HIP one) does the local rearrangement and the twiddle in its own kernels;
+    without them (CPU tensors in tests) torch moves the data and engine.twiddle
+    multiplies."""
     world = dist.get_world_size(group)
     a_loc, b, _ = t.shape
     assert b % world == 0
-    send = t.view(a_loc, world, b // world, 2).permute(1, 2, 0, 3).contiguous()      # [dest][b_dest][a_loc]
-    recv = torch.empty_like(send)
-    dist.all_to_all_single(recv.view(-1), send.view(-1), group=group)                # [src][b_loc][a_src]
+    if engine is not None and hasattr(engine, "pack") and t.is_cuda:
+        send = engine.pack(t, world, twiddle)                                        # [dest][b_dest][a_loc]
+        recv = _all_to_all(send, group)                                              # [src][b_loc][a_src]
+        return engine.unpack(recv, world, b // world, a_loc)                         # [b_loc][src][a_src]
+    if twiddle is not None:
+        engine.twiddle(t, *twiddle)
+    send = t.view(a_loc, world, b // world, 2).permute(1, 2, 0, 3).contiguous()
+    recv = _all_to_all(send, group)
     return recv.view(world, b // world, a_loc, 2).permute(1, 0, 2, 3).reshape(b // world, world * a_loc, 2)
 
 
@@ -202,14 +245,14 @@ def fourstep_ntt(x_local: torch.Tensor, n: int, engine, inverse: bool = False, n
     rank = dist.get_rank(group)
     n1, n2 = fourstep_split(n, world)
     assert x_local.shape == (n // world, 2)
-    t = _a2a_transpose(x_local.view(n1 // world, n2, 2), group)          # [j2_local][j1]
+    t = _a2a_transpose(x_local.view(n1 // world, n2, 2), group, engine)  # [j2_local][j1]
     engine.ntt_batch(t, inverse)                                          # [j2_local][k1]
-    engine.twiddle(t, n, rank * (n2 // world), inverse)                   # * w_n^(j2*k1)
-    t = _a2a_transpose(t, group)                                          # [k1_local][j2]
+    t = _a2a_transpose(t, group, engine,                                  # * w_n^(j2*k1), then [k1_local][j2]
+                       twiddle=(n, rank * (n2 // world), inverse))
     engine.ntt_batch(t, inverse)                                          # [k1_local][k2]
     if not natural_output:
         return t
-    t = _a2a_transpose(t, group)                                          # [k2_local][k1]
+    t = _a2a_transpose(t, group, engine)                                  # [k2_local][k1]
     return t.reshape(n // world, 2)
 
 

@@ -237,3 +237,114 @@ def test_fri_prove_sharded_two_ranks_one_gpu():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sorted(results) == [(0, True, True), (1, True, True)]
+
+
+# ---- the local steps around the all-to-all as HIP kernels ----------------------------------------
+@pytest.mark.parametrize("rows,cols,world", [(1, 8, 2), (24, 256, 4), (100, 96, 3), (512, 4096, 8), (33, 70, 1)])
+def test_fourstep_pack_and_unpack_kernels(engine, rows, cols, world):
+    import torch
+    x = oc.splitmix(rows * cols, rows + cols).reshape(rows, cols, 2)
+    t = torch.from_numpy(x.view(np.int64)).cuda()
+    send = engine.pack(t, world)
+    torch.cuda.synchronize()
+    cpw = cols // world
+    want = x.reshape(rows, world, cpw, 2).transpose(1, 2, 0, 3)                 # [dest][column][row]
+    assert np.array_equal(send.cpu().numpy().view(np.uint64), want)
+    # with the twiddle of the exchange that follows the first set of transforms
+    n_total, row_start = 1 << 22, 37
+    for inverse in (False, True):
+        send = engine.pack(t, world, (n_total, row_start, inverse))
+        torch.cuda.synchronize()
+        got = send.cpu().numpy().view(np.uint64)
+        w = so.primitive_nth_root(n_total)
+        if inverse:
+            w = so.fe_inverse(w)
+        for r in (0, rows // 2, rows - 1):
+            for c in (0, 1, cols // 2, cols - 1):
+                exp = so.fe_mul(oc.to_int(x[r, c]), so.fe_pow(w, (row_start + r) * c))
+                assert oc.to_int(got[c // cpw, c % cpw, r]) == exp
+    # unpack: [source][row][run] -> [row][source][run]
+    run = 5
+    y = oc.splitmix(world * rows * run, 9).reshape(world, rows, run, 2)
+    out = engine.unpack(torch.from_numpy(y.view(np.int64)).cuda(), world, rows, run)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy().view(np.uint64), y.transpose(1, 0, 2, 3).reshape(rows, world * run, 2))
+
+
+def test_fourstep_under_another_torch_stream(group, engine):
+    """The engine follows torch's current stream: tensors produced and consumed on a side stream."""
+    import torch
+    from stark_amd.distributed import fourstep_ntt
+    n = 1 << 16
+    x = oc.splitmix(n, 160)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        t = torch.from_numpy(x.view(np.int64)).cuda()
+        y = fourstep_ntt(t, n, engine, inverse=False)
+        z = fourstep_ntt(y.contiguous(), n, engine, inverse=True)
+    side.synchronize()
+    assert np.array_equal(y.cpu().numpy().view(np.uint64), oc.ntt(x))
+    assert np.array_equal(z.cpu().numpy().view(np.uint64), x)
+    y2 = fourstep_ntt(torch.from_numpy(x.view(np.int64)).cuda(), n, engine)        # and back on the default stream
+    torch.cuda.synchronize()
+    assert np.array_equal(y2.cpu().numpy().view(np.uint64), oc.ntt(x))
+
+
+def _fourstep_two_rank_worker(rank, world, port, q):
+    import sys
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        here = os.path.dirname(os.path.abspath(__file__))
+        for p in (os.path.dirname(here), here, os.path.join(os.path.dirname(here), "oracle")):
+            if p not in sys.path:
+                sys.path.insert(0, p)
+        import oracle_c
+        from stark_amd import Context
+        from stark_amd.distributed import HipEngine, fourstep_ntt, fourstep_split
+        torch.cuda.set_device(0)
+        ctx = Context(0)
+        eng = HipEngine(ctx)
+        ok = True
+        for log_n in (16, 20):
+            n = 1 << log_n
+            x = oracle_c.splitmix(n, 500 + log_n)
+            n1, n2 = fourstep_split(n, world)
+            share = n // world
+            local = torch.from_numpy(x[rank * share:(rank + 1) * share].view(np.int64)).cuda()
+            for inverse in (False, True):
+                ref = oracle_c.ntt(x, inverse)
+                y = fourstep_ntt(local, n, eng, inverse=inverse)
+                torch.cuda.synchronize()
+                ok = ok and np.array_equal(y.cpu().numpy().view(np.uint64), ref[rank * share:(rank + 1) * share])
+                # without the last exchange: rows k1 (this rank's block) x columns k2, X[k1 + n1*k2]
+                yt = fourstep_ntt(local, n, eng, inverse=inverse, natural_output=False)
+                torch.cuda.synchronize()
+                rows = n1 // world
+                want = ref.reshape(n2, n1, 2).transpose(1, 0, 2)[rank * rows:(rank + 1) * rows]
+                ok = ok and np.array_equal(yt.cpu().numpy().view(np.uint64), want)
+        ctx.close()
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_fourstep_two_ranks_one_gpu():
+    """The four-step transform with the HIP engine on two processes sharing the GPU (gloo carries the
+    all-to-all): 2^16 and 2^20 points, forward and inverse, natural and transposed output, against the
+    restatement of NTT::forward / inverse (ntt.rs:25-40) on the whole vector."""
+    import torch.multiprocessing as mp
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    port = 31100 + os.getpid() % 1000
+    procs = [mpc.Process(target=_fourstep_two_rank_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=280) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(results) == [(0, True), (1, True)]
