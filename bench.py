@@ -24,16 +24,44 @@ if ROOT not in sys.path:
 
 LOG_N = 22
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak
-# From the rocprofv3 PMC passes kept under profiles/ (r01_ntt22_pmc_{fetch,write,valu}.csv; see
-# profiles/r01_summary.txt), means over the three pass kernels of a 2^22 transform:
-# HBM-side bytes per launch = 2 x FETCH_SIZE (gfx950 counts half of a wide read stream) + WRITE_SIZE
-PMC_TRAFFIC_BYTES_PER_LAUNCH = (2 * 47915 + 65536) * 1024     # 28 MB of it is the middle pass's twiddle plane
-# 64-bit-class VALU wave-instructions per launch (v_mad_i64_i32 and the 64-bit shifts/adds of the
-# Montgomery product), and all VALU wave-instructions per launch
-PMC_INT64_WAVE_INSTR_PER_LAUNCH = 9661099
-PMC_VALU_WAVE_INSTR_PER_LAUNCH = 17555456
 # a SIMD issues one 64-bit-class integer instruction per 4 cycles: 1024 SIMDs x 2.4 GHz / 4
 VALU_INT64_PEAK_GINSTR_S = 1024 * 2.4 / 4
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc.json")
+
+
+def load_pmc():
+    """Counter figures of the committed profile (profiles/r02_pmc.json, written by
+    tools/make_profile_summary.py from rocprofv3 --pmc passes).  They describe the kernels as they were
+    when the profile was taken: the file carries a hash of the kernel sources, and when that no
+    longer matches the sources next to this script the figures are not quoted (traffic = null)."""
+    from stark_amd._lib import kernel_source_stamp
+    try:
+        with open(PMC_FILE) as f:
+            pmc = json.load(f)
+    except (OSError, ValueError):
+        return None, "no counter profile committed"
+    if pmc.get("kernel_source_sha256") != kernel_source_stamp():
+        return None, "stale: the kernel sources changed after %s was taken" % os.path.relpath(PMC_FILE, ROOT)
+    return pmc, os.path.relpath(PMC_FILE, ROOT)
+
+
+def ntt_roofline(pmc, source, key, n, avg_launch_ms, kernel):
+    """HBM roofline of one pass launch of a 2^k transform, plus the 64-bit-class VALU issue rate."""
+    alg = 32.0 * n                                             # a pass reads and writes every element once
+    achieved = alg / (avg_launch_ms * 1e-3) / 1e9
+    r = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "algorithmic_bytes": int(alg),
+         "kernel": kernel, "avg_launch_us": round(avg_launch_ms * 1e3, 2), "counters": source}
+    if pmc and key in pmc:
+        e = pmc[key]
+        r["traffic"] = int(e["traffic_bytes_per_launch"])
+        i64 = e["int64_wave_instr_per_launch"] / (avg_launch_ms * 1e-3) / 1e9
+        # the butterfly passes are integer-multiply bound: 64-bit multiply-add issue rate (counter
+        # SQ_INSTS_VALU_INT64) against one such instruction per SIMD per 4 cycles
+        r["valu_int64"] = {"achieved": round(i64, 1), "peak": VALU_INT64_PEAK_GINSTR_S, "unit": "Gwave-instr/s",
+                           "frac": round(i64 / VALU_INT64_PEAK_GINSTR_S, 4),
+                           "all_valu_wave_instr_per_launch": int(e["valu_wave_instr_per_launch"])}
+    return r
 
 
 def _ramp(torch, fn, ms=120.0):
@@ -154,12 +182,11 @@ def main():
     assert torch.equal(data, orig), "forward+inverse NTT did not round-trip"
 
     result = None
+    pmc, pmc_source = load_pmc() if rank == 0 else (None, None)
     if rank == 0:
         passes_per_ntt = 3                                     # 2^22 = 2^8 * 2^7 * 2^7
         launches = args.steps * 2 * passes_per_ntt
         avg_launch_ms = kernel_ms_total / launches
-        alg_bytes = 32.0 * n                                   # each pass reads and writes every element once
-        achieved = alg_bytes / (avg_launch_ms * 1e-3) / 1e9
         result = {
             "metric": "128-bit-field NTT throughput, 2^22-point forward+inverse",
             "value": round(world * 2 * n * args.steps / dt / 1e6, 2),
@@ -171,18 +198,8 @@ def main():
             "config": {"workload": "single 2^22-point forward+inverse NTT per GPU, data resident in HBM",
                        "log_n": LOG_N, "elements_per_step": 2 * n, "parallelism": f"independent x{world}",
                        "ramp_ms": args.ramp_ms},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": PMC_TRAFFIC_BYTES_PER_LAUNCH,
-                         "algorithmic_bytes": int(alg_bytes),
-                         "kernel": "ntt_pass_kernel (3 launches per transform)",
-                         "avg_launch_us": round(avg_launch_ms * 1e3, 2),
-                         # the butterfly passes are integer-multiply bound: 64-bit multiply-add issue
-                         # rate (counter SQ_INSTS_VALU_INT64) against one such instruction per SIMD per 4 cycles
-                         "valu_int64": {"achieved": round(PMC_INT64_WAVE_INSTR_PER_LAUNCH / (avg_launch_ms * 1e-3) / 1e9, 1),
-                                        "peak": VALU_INT64_PEAK_GINSTR_S, "unit": "Gwave-instr/s",
-                                        "frac": round(PMC_INT64_WAVE_INSTR_PER_LAUNCH / (avg_launch_ms * 1e-3) / 1e9
-                                                      / VALU_INT64_PEAK_GINSTR_S, 4),
-                                        "all_valu_wave_instr_per_launch": PMC_VALU_WAVE_INSTR_PER_LAUNCH}},
+            "roofline": ntt_roofline(pmc, pmc_source, "ntt22", n, avg_launch_ms,
+                                     "ntt_pass_kernel (3 launches per transform)"),
         }
 
     extra = {}
@@ -199,6 +216,8 @@ def main():
         extra["ntt_2^24_fwd_ms"] = round(_events_ms(torch, lambda: ctx.ntt_dev(d24, n24, False), 10), 4)
         extra["ntt_2^24_inv_ms"] = round(_events_ms(torch, lambda: ctx.ntt_dev(d24, n24, True), 10), 4)
         extra["ntt_2^24_fwd_Melem_s"] = round(n24 / extra["ntt_2^24_fwd_ms"] / 1e3, 1)
+        extra["ntt_2^24_roofline"] = ntt_roofline(pmc, pmc_source, "ntt24", n24, extra["ntt_2^24_fwd_ms"] / 3,
+                                                  "ntt_pass_kernel (3 launches per forward transform, 2^8 x 2^8 x 2^8)")
         # Merkle commitment of 2^24 leaves
         _ramp(torch, lambda: ctx.merkle_commit_fe_dev(d24, n24))
         t0 = time.perf_counter()
@@ -207,6 +226,20 @@ def main():
         torch.cuda.synchronize()
         extra["merkle_2^24_ms"] = round((time.perf_counter() - t0) / 3 * 1e3, 3)
         extra["merkle_2^24_Mhash_s"] = round((2 * n24 - 1) / extra["merkle_2^24_ms"] / 1e3, 1)
+        # the hashing is VALU bound: compressions per second against the compute-only ceiling of the same
+        # BLAKE2b code (tools/hash_bench.hip, measured in the profile run); bytes against what the tree needs
+        ghash = (2 * n24 - 1) / (extra["merkle_2^24_ms"] * 1e-3) / 1e9
+        ceil = (pmc or {}).get("hash_ceiling_ghash_s", {})
+        peak = min(ceil.values()) if ceil else None
+        extra["merkle_roofline"] = {
+            "bound": "valu", "achieved": round(ghash, 2), "peak": peak, "unit": "Gcompression/s",
+            "frac": round(ghash / peak, 4) if peak else None,
+            "compressions": 2 * n24 - 1, "algorithmic_bytes": 144 * n24,
+            "algorithmic_bytes_note": "48 N leaf level (16 N read, 32 N written) + 96 N node levels, every level through HBM",
+            "traffic": int(pmc["merkle24"]["traffic_bytes_per_call"]) if pmc and "merkle24" in pmc else None,
+            "hbm_GB_s": round(144 * n24 / (extra["merkle_2^24_ms"] * 1e-3) / 1e9, 1),
+            "launches_per_commit": (pmc or {}).get("merkle24", {}).get("launches_per_call"),
+            "counters": pmc_source}
         # FRI commit on a 2^24 codeword (blowup 4, 17 colinearity tests: 18 roots, 17 folds) through
         # the C++ host mirror of Fri::commit: the Fiat-Shamir transcript is its native ProofStream
         from stark_amd import hostlib
@@ -222,6 +255,21 @@ def main():
             fri_once()
         torch.cuda.synchronize()
         extra["fri_commit_2^24_ms"] = round((time.perf_counter() - t0) / 3 * 1e3, 3)
+        # 18 layers of 2^24 .. 2^7 elements: one tree each (2 n_r - 1 compressions) and 17 folds of 32 n_r bytes;
+        # every root goes to the host transcript and comes back as the next fold's challenge
+        fri_comp = sum(2 * (n24 >> r) - 1 for r in range(18))
+        fri_fold_bytes = sum(32 * (n24 >> r) for r in range(17))
+        fri_tree_bytes = sum(144 * (n24 >> r) for r in range(18))
+        gh = fri_comp / (extra["fri_commit_2^24_ms"] * 1e-3) / 1e9
+        extra["fri_commit_roofline"] = {
+            "bound": "valu", "achieved": round(gh, 2), "peak": peak, "unit": "Gcompression/s",
+            "frac": round(gh / peak, 4) if peak else None, "compressions": fri_comp,
+            "algorithmic_bytes": fri_fold_bytes + fri_tree_bytes, "fold_bytes": fri_fold_bytes, "tree_bytes": fri_tree_bytes,
+            "traffic": int(pmc["fri24"]["traffic_bytes_per_call"]) if pmc and "fri24" in pmc else None,
+            "host_round_trips": 17, "launches_per_commit": (pmc or {}).get("fri24", {}).get("launches_per_call"),
+            "round_trip_note": "per round: root written to host-mapped memory by the kernel that computes it, stream "
+                               "synchronised, hex + SHAKE256 + sample on the host, next fold launched",
+            "counters": pmc_source}
 
         # Fri::prove = the commit plus the query phase answered from the resident layers (one round
         # trip per round); the codeword is a real one (2^22 coefficients extended to 2^24 points)
@@ -267,6 +315,44 @@ def main():
         extra["coset_lde_16x2^20_to_2^22_ms"] = round(_events_ms(torch, lde, 5), 3)
         extra["coset_lde_Melem_s_out"] = round((cols << 22) / extra["coset_lde_16x2^20_to_2^22_ms"] / 1e3, 1)
         del coeffs, out
+        # the scaled workload: Stark::prove of a 2^20-row Rescue-Prime chain (2 registers, FRI domain 2^24,
+        # blowup 4, 2 colinearity tests) with the polynomial algebra on the device; the trace itself (the
+        # computation being proven) is made once on the host and is not part of the proof time
+        try:
+            import ctypes as C
+            import hashlib as _hl
+            hostlib.lib.sh_chain_new.restype = C.c_void_p
+            hostlib.lib.sh_chain_random_bytes.restype = C.c_size_t
+            ctx.trim()                                            # the prover allocates through its own context
+            t0 = time.perf_counter()
+            job = C.c_void_p(hostlib.lib.sh_chain_new(hostlib.fe(2024), C.c_size_t(1 << 20), C.c_size_t(4), C.c_size_t(2),
+                                                      C.c_size_t(2)))
+            if not job:
+                raise RuntimeError(hostlib.lib.sh_last_panic().decode())
+            extra["stark_trace_and_tables_2^20_s"] = round(time.perf_counter() - t0, 2)
+            rb = _hl.shake_256(b"bench").digest(hostlib.lib.sh_chain_random_bytes(job))
+            rbuf = (C.c_uint8 * len(rb)).from_buffer_copy(rb)
+            proof = (C.c_uint8 * (1 << 20))()
+            names = ("host", "interpolate", "quotients", "lde", "merkle", "fri", "openings", "total")
+            best = None
+            for _ in range(4):
+                plen = C.c_size_t(len(proof))
+                tm = (C.c_double * 8)()
+                hostlib.chk(hostlib.lib.sh_chain_prove(job, rbuf, C.c_size_t(len(rb)), proof, C.byref(plen), tm))
+                if best is None or tm[7] < best[7]:
+                    best = list(tm)
+            out_el = (C.c_uint64 * 2)()
+            hostlib.chk(hostlib.lib.sh_chain_output(job, out_el))
+            t0 = time.perf_counter()
+            accepted = hostlib.lib.sh_chain_verify(job, out_el, proof, plen)
+            extra["stark_verify_2^20_ms"] = round((time.perf_counter() - t0) * 1e3, 1)
+            assert accepted == 1, "the verifier rejected the 2^20-row proof"
+            extra["stark_prove_2^20_ms"] = round(best[7], 2)
+            extra["stark_prove_2^20_split_ms"] = {k: round(v, 2) for k, v in zip(names, best)}
+            extra["stark_proof_2^20_bytes"] = plen.value
+            hostlib.lib.sh_chain_free(job)
+        except Exception as e:  # noqa: BLE001 - a side measurement must not lose the headline line
+            extra["stark_prove_2^20_error"] = repr(e)
 
     # side measurements every rank takes part in: the batched-LDE workload (64 columns of 2^20
     # coefficients -> 2^22 points each, one Merkle root per column), sharded column-wise with no

@@ -67,7 +67,9 @@ int32_t stark_ctx_synchronize(stark_ctx* ctx);
 int32_t stark_ctx_trim(stark_ctx* ctx);
 const char* stark_last_error(void);
 
-/* ---- device memory helpers (for callers that keep vectors resident) ------ */
+/* ---- device memory helpers (for callers that keep vectors resident) ------
+ * Freed blocks stay in the context's cache for the next stark_dev_alloc of the
+ * same size (stark_ctx_trim gives them back to the runtime). */
 int32_t stark_dev_alloc(stark_ctx* ctx, size_t bytes, void** dptr);
 int32_t stark_dev_free(stark_ctx* ctx, void* dptr);
 int32_t stark_copy_h2d(stark_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);

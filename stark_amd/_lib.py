@@ -84,6 +84,21 @@ SIGNATURES = {
 _lib = None
 
 
+def kernel_source_stamp() -> str:
+    """SHA-256 over the kernel and C-ABI sources (stark_amd/csrc/*.hip, *.hpp, in name order).  Profiles
+    taken for one state of the kernels are stamped with it, and a counter figure is only quoted next
+    to a measurement when the stamp still matches the sources the library was built from."""
+    import hashlib
+    d = os.path.join(_HERE, "csrc")
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".hpp")):
+            h.update(name.encode())
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(f.read())
+    return h.hexdigest()
+
+
 def preload_hip_runtime() -> None:
     """A process must hold ONE HIP runtime.  A PyTorch-ROCm wheel carries its own
     libamdhip64.so (and HSA runtime) and asks for it by a name that does not

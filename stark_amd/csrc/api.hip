@@ -104,6 +104,7 @@ struct stark_ctx {
     size_t scratch_elems = 0;
     std::multimap<size_t, void*> pool;                 // cached device blocks by size
     size_t pool_large_bytes = 0;                       // bytes of the cached blocks of at least 1 MiB
+    std::map<void*, size_t> dev_blocks;                // blocks handed out by stark_dev_alloc, by address
     void* pinned = nullptr;                            // small pinned staging buffer (4 KiB)
     void* pin_io = nullptr;                            // 2 x 64 KiB host-mapped: small transforms run on it in place
     std::recursive_mutex mu;
@@ -181,7 +182,7 @@ static size_t pool_bucket(size_t bytes)
 // Blocks of at least 1 MiB that the cache may hold: a count and a byte total (a 2^24 FRI commit
 // parks a 0.5 GiB and a 2 GiB arena, a 2^26 one 2 + 8 GiB).
 constexpr size_t POOL_LARGE = (size_t)1 << 20;
-constexpr size_t POOL_MAX_LARGE_BLOCKS = 16;
+constexpr size_t POOL_MAX_LARGE_BLOCKS = 64;
 constexpr size_t POOL_MAX_LARGE_BYTES = (size_t)8 << 30;
 
 static void pool_drop(stark_ctx* ctx)
@@ -872,7 +873,11 @@ extern "C" int32_t stark_dev_alloc(stark_ctx* ctx, size_t bytes, void** dptr)
 {
     CtxGuard guard_(ctx);
     if (!ctx || !dptr) return fail(STARK_EARG, "null argument");
-    HIP_TRY(malloc_retry(ctx, dptr, bytes ? bytes : 16));
+    // through the block cache: a prover allocates the same few large vectors proof after proof, and a
+    // hipMalloc / hipFree pair of that size costs more than the kernels that use it
+    if (bytes == 0) bytes = 16;
+    ST_TRY(pool_alloc(ctx, bytes, dptr));
+    ctx->dev_blocks[*dptr] = bytes;
     return STARK_OK;
 }
 
@@ -897,8 +902,15 @@ extern "C" int32_t stark_dev_free(stark_ctx* ctx, void* dptr)
 {
     CtxGuard guard_(ctx);
     if (!ctx) return fail(STARK_EARG, "null context");
+    if (!dptr) return STARK_OK;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    HIP_TRY(hipFree(dptr));
+    auto it = ctx->dev_blocks.find(dptr);
+    if (it == ctx->dev_blocks.end()) {
+        HIP_TRY(hipFree(dptr));
+        return STARK_OK;
+    }
+    pool_free(ctx, dptr, it->second);
+    ctx->dev_blocks.erase(it);
     return STARK_OK;
 }
 
@@ -1180,9 +1192,14 @@ extern "C" int32_t stark_poly_degree_dev(stark_ctx* ctx, const uint64_t* coeffs_
 {
     CtxGuard guard_(ctx);
     if (!ctx || (n && !coeffs_dev) || !degree_out) return fail(STARK_EARG, "null argument");
-    unsigned long long* mail = (unsigned long long*)((uint8_t*)ctx->pinned + 1024);      // host-mapped pinned word
-    *mail = 0;
-    HIP_TRY(launch_poly_degree((const fe*)coeffs_dev, n, mail, ctx->stream));
+    // the kernel's atomics go to a word of device memory (one per wave that saw a nonzero coefficient; against
+    // host memory each would cross the link), which is then copied out
+    unsigned long long* mail = (unsigned long long*)((uint8_t*)ctx->pinned + 1024);
+    DevBuf word(ctx);
+    ST_TRY(word.alloc(sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(word.p, 0, sizeof(unsigned long long), ctx->stream));
+    HIP_TRY(launch_poly_degree((const fe*)coeffs_dev, n, (unsigned long long*)word.p, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(mail, word.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     const unsigned long long r = *mail;
     *degree_out = r ? (size_t)(r - 1) : 0;                   // univariate_poly.rs:69-85: the zero polynomial has degree 0

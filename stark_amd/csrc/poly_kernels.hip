@@ -182,12 +182,18 @@ __global__ __launch_bounds__(256) void poly_degree_kernel(const fe* __restrict__
     unsigned long long best = 0;
     for (; i < n; i += step)
         if (!fe_is_zero(c[i])) best = i + 1;
-    // one atomic per wave: the largest candidate of the 64 lanes
+    // one atomic per workgroup at most: the largest candidate of each wave, then of the four waves
     for (int off = 32; off >= 1; off >>= 1) {
         const unsigned long long o = __shfl_xor(best, off);
         best = o > best ? o : best;
     }
-    if ((threadIdx.x & 63) == 0 && best) atomicMax(result, best);
+    __shared__ unsigned long long wave_best[4];
+    if ((threadIdx.x & 63) == 0) wave_best[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; w++) best = wave_best[w] > best ? wave_best[w] : best;
+        if (best) atomicMax(result, best);
+    }
 }
 
 hipError_t launch_poly_degree(const fe* c, uint64_t n, unsigned long long* result_dev, hipStream_t s)

@@ -188,6 +188,10 @@ struct ScaledStark {
     FieldElement generator, omega, omicron;
     Fri fri;
     GeometricDomain geo;
+    // kept from one proof to the next: the transition zeroifier's coefficients on the device (they depend
+    // on the trace length only) and the staging buffer of the randomizer's raw bytes
+    mutable std::unique_ptr<DeviceVector> tz_coeffs;
+    mutable std::vector<uint8_t> random_staging;
 
     // stark.rs:34-86 without the assertion on omicron's value (:65) and without the table of
     // omicron's powers (:63), which only the zeroifier needed
@@ -449,13 +453,12 @@ struct ScaledStark {
             if (K)
                 check(stark_coset_lde_batch_dev(ctx, constants->words(), T - 1, T - 1, K, n_q, gen_w,
                                                 cols.words((1 + R) * n_q), n_q));
-            {
-                DeviceVector tz(T);
-                tz.upload(geo.zeroifier(T - 1));               // :134-137
-                check(stark_coset_lde_batch_dev(ctx, tz.words(), T, T, 1, n_q, gen_w, tz_values.words(), n_q));
-                check(stark_vec_inv_dev(ctx, tz_values.words(), tz_values.words(), n_q));
-                check(stark_ctx_synchronize(ctx));
+            if (!tz_coeffs) {
+                tz_coeffs.reset(new DeviceVector(T));
+                tz_coeffs->upload(geo.zeroifier(T - 1));       // :134-137
             }
+            check(stark_coset_lde_batch_dev(ctx, tz_coeffs->words(), T, T, 1, n_q, gen_w, tz_values.words(), n_q));
+            check(stark_vec_inv_dev(ctx, tz_values.words(), tz_values.words(), n_q));
             // variables: x, registers now, registers one step on (rotation 1), constants
             std::vector<const uint64_t*> ptrs(n_vars);
             std::vector<size_t> rot(n_vars, 0);
@@ -485,10 +488,11 @@ struct ScaledStark {
         // ---- randomizer polynomial (:344-360)
         DeviceVector randomizer(max_deg + 1), rz_codeword(n_fri);
         {
-            std::vector<uint8_t> bytes(17 * (max_deg + 1));
-            rng(bytes.data(), bytes.size());
-            DeviceBuffer raw(bytes.size());
-            check(stark_copy_h2d(ctx, raw.p, bytes.data(), bytes.size()));
+            const size_t n_bytes = 17 * (max_deg + 1);
+            if (random_staging.size() < n_bytes) random_staging.resize(n_bytes);    // tens of megabytes, touched once
+            rng(random_staging.data(), n_bytes);
+            DeviceBuffer raw(n_bytes);
+            check(stark_copy_h2d(ctx, raw.p, random_staging.data(), n_bytes));
             check(stark_sample_bytes_dev(ctx, (const uint8_t*)raw.p, 17, max_deg + 1, 1, randomizer.words()));
             check(stark_ctx_synchronize(ctx));
         }

@@ -1,59 +1,142 @@
-"""Writes profiles/<round>_summary.txt from the CSVs next to it.
-usage: python3 tools/make_profile_summary.py r01"""
-import collections, csv, json, os, sys
+"""Turns the raw output of tools/profile_round.sh into the files kept under profiles/:
+<round>_pmc.json (the counter figures bench.py quotes, stamped with the kernel sources they were taken
+for), <round>_summary.txt, and copies of the CSVs they come from.
 
-rnd = sys.argv[1]
-P = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+usage: python3 tools/make_profile_summary.py <round, e.g. r02> <raw dir, e.g. gpurun_out/prof_r02>"""
+import collections
+import csv
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from stark_amd._lib import kernel_source_stamp  # noqa: E402
+
+rnd, raw = sys.argv[1], os.path.abspath(sys.argv[2])
+P = os.path.join(ROOT, "profiles")
+WORKLOADS = {"ntt22": 5, "ntt24": 5, "merkle24": 3, "fri24": 3}      # repetitions prof_driver.py ran (profile_round.sh)
+SETUP_KERNELS = ("ntt_plane_kernel", "rocclr", "fillBuffer", "copyBuffer")
 
 
-def pmc(path):
+def find(dirname, suffix):
+    for base, _, files in os.walk(os.path.join(raw, dirname)):
+        for f in files:
+            if f.endswith(suffix):
+                return os.path.join(base, f)
+    raise FileNotFoundError(f"{dirname}/*{suffix}")
+
+
+def short(name):
+    name = name.replace("void ", "").replace("starkk::", "")
+    return name[:name.index("(")] if "(" in name else name
+
+
+def pmc(workload, group):
+    """{kernel: {counter: [value per dispatch]}} of one counter pass, set-up kernels dropped."""
+    path = find(f"{workload}_{group}", "counter_collection.csv")
+    shutil.copy(path, os.path.join(P, f"{rnd}_{workload}_pmc_{group}.csv"))
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(path)):
-        agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
-    return {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in agg.items() if "ntt_pass" in k}
+        k = short(r["Kernel_Name"])
+        if any(s in k for s in SETUP_KERNELS):
+            continue
+        agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return agg
+
+
+def kernel_stats(workload):
+    path = find(f"{workload}_kt", "kernel_stats.csv")
+    shutil.copy(path, os.path.join(P, f"{rnd}_{workload}_kernel_stats.csv"))
+    return {short(r["Name"]): (int(r["Calls"]), float(r["TotalDurationNs"]), float(r["AverageNs"]))
+            for r in csv.DictReader(open(path))}
 
 
 out = []
 w = out.append
-w(f"Profile summary {rnd} (MI355X, gfx950, ROCm 7.2) -- generated by tools/make_profile_summary.py from the CSVs next to this file")
-w("collected by tools/profile_round.sh: rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20,")
-w("then one rocprofv3 --pmc run per counter group over python3 tools/prof_driver.py ntt22 5 (and ntt24 5)")
+data = {"kernel_source_sha256": kernel_source_stamp(),
+        "commit": subprocess.run(["git", "-C", ROOT, "rev-parse", "HEAD"], capture_output=True, text=True).stdout.strip(),
+        "note": "FETCH_SIZE on gfx950 reports half of a wide coalesced read stream: reads = 2 x FETCH_SIZE (KB); "
+                "WRITE_SIZE (KB) is exact for 16-byte-per-lane stores. Per-launch / per-call means over the profiled "
+                "repetitions; each counter group was collected in a rocprofv3 run of its own."}
+w(f"Profile summary {rnd} (MI355X, gfx950, ROCm 7.2) -- written by tools/make_profile_summary.py from the output of")
+w("tools/profile_round.sh: rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20, then per workload")
+w("(tools/prof_driver.py ntt22|ntt24|merkle24|fri24) one rocprofv3 --pmc run per counter group and one kernel trace.")
+w(f"kernel sources sha256 {data['kernel_source_sha256'][:16]}..., commit {data['commit'][:10]}")
 w("")
-line = json.loads(open(os.path.join(P, f"{rnd}_bench_line.json")).read().strip().splitlines()[-1])
+bench_log = open(os.path.join(raw, "bench.log")).read().strip().splitlines()
+line = json.loads([l for l in bench_log if l.startswith("{")][-1])
+open(os.path.join(P, f"{rnd}_bench_line.json"), "w").write(json.dumps(line) + "\n")
 w("bench line of the profiled run: value %.1f %s, %.4f ms/step, roofline avg_launch_us %.2f" %
   (line["value"], line["unit"], line["ms_per_step"], line["roofline"]["avg_launch_us"]))
 w("")
-w("%-100s %6s %14s %12s %6s" % ("kernel", "calls", "total_ns", "avg_ns", "pct"))
+shutil.copy(find("bench", "kernel_stats.csv"), os.path.join(P, f"{rnd}_bench_kernel_stats.csv"))
+shutil.copy(os.path.join(raw, "bench_ntt_launches_by_grid.csv"), os.path.join(P, f"{rnd}_bench_ntt_launches_by_grid.csv"))
+w("%-92s %6s %14s %12s %6s" % ("kernel (bench run)", "calls", "total_ns", "avg_ns", "pct"))
 for r in csv.DictReader(open(os.path.join(P, f"{rnd}_bench_kernel_stats.csv"))):
-    if float(r["Percentage"]) < 0.5:
-        continue
-    w("%-100s %6s %14s %12.0f %6.2f" % (r["Name"][:100], r["Calls"], r["TotalDurationNs"], float(r["AverageNs"]),
-                                       float(r["Percentage"])))
-by_grid = os.path.join(P, f"{rnd}_bench_ntt_launches_by_grid.csv")
-if os.path.exists(by_grid):
-    w("")
-    w("ntt_pass_kernel launches of the same run split by size (the stats above mix 2^22, 2^24 and batched launches);")
-    w("the three 2^22 rows are the launches bench.py's roofline.avg_launch_us averages:")
-    for r in csv.DictReader(open(by_grid)):
-        w("  %-40s %9s elements %6s calls  avg %8s ns  min %8s ns" % (r["kernel"], r["elements"], r["calls"], r["avg_ns"], r["min_ns"]))
+    if float(r["Percentage"]) >= 0.5:
+        w("%-92s %6s %14s %12.0f %6.2f" % (short(r["Name"])[:92], r["Calls"], r["TotalDurationNs"], float(r["AverageNs"]),
+                                          float(r["Percentage"])))
 w("")
-w("2^22 forward or inverse transform = ntt_pass_kernel<4,0,false,0> + <3,1,false,2> + <3,2,false,0> (the middle one reads a 20 B/element twiddle plane)")
-f = pmc(os.path.join(P, f"{rnd}_ntt22_pmc_fetch.csv"))
-wr = pmc(os.path.join(P, f"{rnd}_ntt22_pmc_write.csv"))
-v = pmc(os.path.join(P, f"{rnd}_ntt22_pmc_valu.csv"))
-tot_f = tot_w = tot_i64 = tot_valu = 0.0
-for k in f:
-    name = k[k.index("ntt_pass_kernel"):k.index("(")]
-    w("  %-44s FETCH_SIZE %9.1f KB  WRITE_SIZE %9.1f KB  SQ_INSTS_VALU %11.0f  INT64 %11.0f  INT32 %10.0f" %
-      (name, f[k]["FETCH_SIZE"], wr[k]["WRITE_SIZE"], v[k]["SQ_INSTS_VALU"], v[k]["SQ_INSTS_VALU_INT64"],
-       v[k]["SQ_INSTS_VALU_INT32"]))
-    tot_f += f[k]["FETCH_SIZE"]; tot_w += wr[k]["WRITE_SIZE"]
-    tot_i64 += v[k]["SQ_INSTS_VALU_INT64"]; tot_valu += v[k]["SQ_INSTS_VALU"]
-n = len(f)
-w("  FETCH_SIZE on gfx950 reports half of a wide coalesced read stream, so reads = 2 x FETCH_SIZE.")
-w("  mean HBM-side traffic per launch = 2 x %.0f KB + %.0f KB = %.1f MB; algorithmic bytes per launch = 32 B x 2^22 = 134.2 MB" %
-  (tot_f / n, tot_w / n, (2 * tot_f / n + tot_w / n) * 1024 / 1e6))
-w("  mean 64-bit-class VALU instructions per launch (v_mad_i64_i32, 64-bit shifts and adds) = %.0f wave-instructions," % (tot_i64 / n))
-w("  of %.0f VALU wave-instructions in all" % (tot_valu / n))
+w("ntt_pass_kernel launches of the bench run split by size:")
+for r in csv.DictReader(open(os.path.join(P, f"{rnd}_bench_ntt_launches_by_grid.csv"))):
+    w("  %-40s %9s elements %6s calls  avg %8s ns  min %8s ns" % (r["kernel"], r["elements"], r["calls"], r["avg_ns"], r["min_ns"]))
+
+for wl, reps in WORKLOADS.items():
+    f, wr, v, kt = pmc(wl, "fetch"), pmc(wl, "write"), pmc(wl, "valu"), kernel_stats(wl)
+    w("")
+    w(f"== {wl}: {reps} repetitions of tools/prof_driver.py {wl}")
+    entry = {"kernels": {}}
+    tot_read = tot_write = tot_i64 = tot_valu = 0.0
+    launches = 0
+    for k in sorted(f):
+        fs, ws = f[k]["FETCH_SIZE"], wr[k]["WRITE_SIZE"]
+        vi, v64 = v[k]["SQ_INSTS_VALU"], v[k]["SQ_INSTS_VALU_INT64"]
+        calls, _, avg_ns = kt.get(k, (len(fs), 0.0, 0.0))
+        entry["kernels"][k] = {"launches": len(fs), "fetch_kb_mean": sum(fs) / len(fs), "write_kb_mean": sum(ws) / len(ws),
+                               "valu_wave_instr_mean": sum(vi) / len(vi), "int64_wave_instr_mean": sum(v64) / len(v64),
+                               "avg_ns": avg_ns}
+        w("  %-44s %4d launches  FETCH_SIZE %10.1f KB  WRITE_SIZE %10.1f KB  SQ_INSTS_VALU %12.0f  INT64 %12.0f  avg %9.0f ns" %
+          (k[:44], len(fs), sum(fs) / len(fs), sum(ws) / len(ws), sum(vi) / len(vi), sum(v64) / len(v64), avg_ns))
+        tot_read += 2 * sum(fs) * 1024
+        tot_write += sum(ws) * 1024
+        tot_i64 += sum(v64)
+        tot_valu += sum(vi)
+        launches += len(fs)
+    if wl.startswith("ntt"):
+        passes = [k for k in f if "ntt_pass_kernel" in k]
+        n_l = sum(len(f[k]["FETCH_SIZE"]) for k in passes)
+        tr = sum(2 * sum(f[k]["FETCH_SIZE"]) + sum(wr[k]["WRITE_SIZE"]) for k in passes) * 1024 / n_l
+        entry["traffic_bytes_per_launch"] = tr
+        entry["int64_wave_instr_per_launch"] = sum(sum(v[k]["SQ_INSTS_VALU_INT64"]) for k in passes) / n_l
+        entry["valu_wave_instr_per_launch"] = sum(sum(v[k]["SQ_INSTS_VALU"]) for k in passes) / n_l
+        entry["pass_launches_profiled"] = n_l
+        n = 1 << int(wl[3:])
+        w("  mean over the %d pass launches: HBM-side traffic %.1f MB per launch (algorithmic 32 B x 2^%s = %.1f MB), "
+          "%.0f 64-bit-class of %.0f VALU wave-instructions" % (n_l, tr / 1e6, wl[3:], 32 * n / 1e6,
+                                                                 entry["int64_wave_instr_per_launch"], entry["valu_wave_instr_per_launch"]))
+    else:
+        entry["traffic_bytes_per_call"] = (tot_read + tot_write) / reps
+        entry["valu_wave_instr_per_call"] = tot_valu / reps
+        entry["launches_per_call"] = launches / reps
+        w("  per call: HBM-side traffic %.1f MB in %.1f launches, %.0f VALU wave-instructions" %
+          (entry["traffic_bytes_per_call"] / 1e6, entry["launches_per_call"], entry["valu_wave_instr_per_call"]))
+    data[wl] = entry
+
+hb = os.path.join(raw, "hash_bench.txt")
+if os.path.exists(hb):
+    shutil.copy(hb, os.path.join(P, f"{rnd}_hash_bench.txt"))
+    w("")
+    w("== tools/hash_bench.hip (compute-only ceiling of the BLAKE2b compressions, chained in registers)")
+    ceil = {}
+    for l in open(hb):
+        w("  " + l.rstrip())
+        if "Ghash/s" in l and "compute only" in l:
+            ceil[l.split("(")[0].strip()] = float(l.split("Ghash/s")[0].split()[-1])
+    data["hash_ceiling_ghash_s"] = ceil
+with open(os.path.join(P, f"{rnd}_pmc.json"), "w") as fjson:
+    json.dump(data, fjson, indent=1, sort_keys=True)
 open(os.path.join(P, f"{rnd}_summary.txt"), "w").write("\n".join(out) + "\n")
 print("\n".join(out))

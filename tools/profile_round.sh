@@ -1,17 +1,23 @@
 #!/bin/bash
-# Collects the profiles kept under profiles/: kernel stats of the bench command and the PMC
-# passes of the 2^22 transform (each counter group in a run of its own).
+# Collects what profiles/<round>_* is made from: kernel stats of the bench command, the PMC passes of
+# the 2^22 and 2^24 transforms, of the 2^24 Merkle commitment and of the 2^24 FRI commit (each counter
+# group in a run of its own), and the compute-only hash ceiling of tools/hash_bench.hip.
 # usage (on the GPU box, from the repository root): bash tools/profile_round.sh <out_dir>
 set -e
 R=$PWD
 OUT=$R/${1:-gpurun_out/prof}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench -o bench -- python3 $R/bench.py --steps 20 > $OUT/bench.log 2>&1
-timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch -o fetch --output-format csv -- python3 $R/tools/prof_driver.py ntt22 5 > $OUT/fetch.log 2>&1
-timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE -d $OUT/write -o write --output-format csv -- python3 $R/tools/prof_driver.py ntt22 5 > $OUT/write.log 2>&1
-timeout -s KILL 120 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_INT32 SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY -d $OUT/valu -o valu --output-format csv -- python3 $R/tools/prof_driver.py ntt22 5 > $OUT/valu.log 2>&1
-timeout -s KILL 120 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_INT32 SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT -d $OUT/valu24 -o valu24 --output-format csv -- python3 $R/tools/prof_driver.py ntt24 5 > $OUT/valu24.log 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench -o bench -- python3 $R/bench.py --steps 20 > $OUT/bench.log 2>&1
+VALU="SQ_INSTS_VALU SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_INT32 SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY"
+for W in ntt22 ntt24 merkle24 fri24; do
+    REPS=5; if [ $W = merkle24 ] || [ $W = fri24 ]; then REPS=3; fi
+    timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE -d $OUT/${W}_fetch -o fetch --output-format csv -- python3 $R/tools/prof_driver.py $W $REPS > $OUT/${W}_fetch.log 2>&1
+    timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE -d $OUT/${W}_write -o write --output-format csv -- python3 $R/tools/prof_driver.py $W $REPS > $OUT/${W}_write.log 2>&1
+    timeout -s KILL 120 rocprofv3 --pmc $VALU -d $OUT/${W}_valu -o valu --output-format csv -- python3 $R/tools/prof_driver.py $W $REPS > $OUT/${W}_valu.log 2>&1
+    timeout -k 10 120 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${W}_kt -o kt -- python3 $R/tools/prof_driver.py $W $REPS > $OUT/${W}_kt.log 2>&1
+done
+if [ -x $R/tools/_build/hash_bench ]; then timeout -k 10 60 $R/tools/_build/hash_bench > $OUT/hash_bench.txt 2>&1; fi
 python3 - "$OUT" <<'PY'
 # ntt_pass_kernel launches of the bench run split by grid size (copied to profiles/<round>_bench_ntt_launches_by_grid.csv)
 import collections, csv, sys
@@ -26,4 +32,4 @@ with open(out + "/bench_ntt_launches_by_grid.csv", "w") as f:
     for (name, g), v in sorted(agg.items(), key=lambda kv: (kv[0][1], kv[0][0])):
         f.write('"%s",%d,%d,%d,%.0f,%d\n' % (name, g, g * 16, len(v), sum(v) / len(v), min(v)))
 PY
-ls $OUT/*
+ls $OUT
