@@ -18,7 +18,8 @@ using starkh::digest;
 constexpr int TILE_ELEMS = 4096;      // elements per workgroup tile
 constexpr int TILE_THREADS = 256;
 constexpr int SMALL_MAX_LOG = 12;     // n <= 4096 fits one workgroup's LDS (ntt_small_kernel)
-constexpr int PASS_MIN_LOG = 12;      // from n = 4096 on the tiled multi-pass kernels are faster (two passes of 2^6)
+constexpr int PASS_MIN_LOG = 10;      // from n = 1024 on the tiled multi-pass kernels are faster (two passes of 2^5 or
+                                      // 2^6; below 4096 points several transforms of a batch share a tile)
 constexpr int MAX_PASSES = 4;
 
 // One global pass of the multi-pass NTT.  n = R_0 * R_1 * ... * R_{P-1}; pass q
@@ -43,6 +44,7 @@ struct PassArgs {
     uint32_t h;            // log2 of the last radix
     uint32_t nprev;        // q
     uint32_t rprev[MAX_PASSES];   // log2 R_u, u < q
+    uint32_t n_batch;             // transforms in the launch (set by launch_ntt_pass)
     // Pass before the last only: its outgoing twiddle omega_n^(j_next * K) has all of n as exponent
     // range.  If set, plane[5 i .. 5 i + 4] holds the five limbs of the twiddle of output element i
     // (same index as dst); otherwise the kernel multiplies hi and lo entries together per element.

@@ -140,41 +140,71 @@ __device__ __forceinline__ fe finish(const fe5& x)
     return o;
 }
 
+// Which transform of the batch, and which column of it in this pass (row in PASS_LAST), a tile's column c is.
+// Transforms of at least 4096 points own whole tiles: the transform index is the same for the whole
+// workgroup.  Shorter ones (SMALL) share a tile, 4096 / n of them side by side, and the index varies
+// with c; a tile may then reach past the end of the batch.
+template <int RA, bool SMALL>
+__device__ __forceinline__ void locate(const PassArgs& a, uint64_t tile, int c, uint64_t& batch, uint64_t& f)
+{
+    constexpr int C = 1 << (8 - RA);
+    if constexpr (SMALL) {
+        const uint32_t cl = a.log_n - a.r;                     // log2 of the columns of one transform in this pass
+        const uint64_t fg = tile * C + (uint64_t)c;
+        batch = fg >> cl;
+        f = fg & (((uint64_t)1 << cl) - 1);
+    } else {
+        const uint32_t ltiles = a.log_n - 12;
+        batch = tile >> ltiles;
+        f = (tile & (((uint64_t)1 << ltiles) - 1)) * C + (uint64_t)c;
+    }
+}
+
 // Issue the 16 global loads of one thread for one tile (round-1 layout).
 // tile enumerates (batch, tile-in-transform); rows past n_src of a first pass
 // are the zero padding and are not read.
-template <int RA, int MODE>
+template <int RA, int MODE, bool SMALL>
 __device__ __forceinline__ void load_tile(fe (&raw)[16], const PassArgs& a, uint64_t tile, int t)
 {
     constexpr int M1 = 1 << RA;
     constexpr int G1 = 16 / M1;
     constexpr int LOGC = 8 - RA;
     constexpr int C = 1 << LOGC;
-    const uint32_t ltiles = a.log_n - 12;
-    const uint64_t batch = tile >> ltiles;
-    const uint32_t tx = (uint32_t)(tile & (((uint64_t)1 << ltiles) - 1));
-    const fe* __restrict__ src = a.src + batch * a.src_batch_stride;
 #pragma unroll
     for (int g = 0; g < G1; g++) {
         const int q1 = t + TILE_THREADS * g;
         if constexpr (MODE == PASS_LAST) {
             const int c = q1 >> 4, jb = q1 & 15;
-            const uint32_t b = tx * C + c;                         // low part of the output index
-            const uint64_t row = (uint64_t)k_to_prefix(b, a) << a.r;
+            uint64_t batch, b;                                     // b: low part of the output index
+            locate<RA, SMALL>(a, tile, c, batch, b);
+            const fe* __restrict__ src = a.src + batch * a.src_batch_stride;
+            const uint64_t row = (uint64_t)k_to_prefix((uint32_t)b, a) << a.r;
 #pragma unroll
-            for (int ja = 0; ja < M1; ja++) raw[g * M1 + ja] = src[row + ja * 16 + jb];
+            for (int ja = 0; ja < M1; ja++) {
+                if constexpr (SMALL) {
+                    raw[g * M1 + ja] = fe_zero();
+                    if (batch < a.n_batch) raw[g * M1 + ja] = src[row + ja * 16 + jb];
+                } else {
+                    raw[g * M1 + ja] = src[row + ja * 16 + jb];
+                }
+            }
         } else {
             const int jb = q1 >> LOGC, c = q1 & (C - 1);
-            const uint64_t f = (uint64_t)tx * C + c;               // flat column of this pass
+            uint64_t batch, f;                                     // f: flat column of this pass
+            locate<RA, SMALL>(a, tile, c, batch, f);
+            const fe* __restrict__ src = a.src + batch * a.src_batch_stride;
             const uint64_t pre = f >> a.log_s;
             const uint64_t col = f & (((uint64_t)1 << a.log_s) - 1);
             const uint64_t base = (pre << (a.r + a.log_s)) + col;
 #pragma unroll
             for (int ja = 0; ja < M1; ja++) {
                 const uint64_t idx = base + ((uint64_t)(ja * 16 + jb) << a.log_s);
-                if constexpr (MODE == PASS_FIRST) {
+                if constexpr (MODE == PASS_FIRST || SMALL) {
                     raw[g * M1 + ja] = fe_zero();
-                    if (idx < a.n_src) raw[g * M1 + ja] = src[idx];
+                    bool ok = true;
+                    if constexpr (MODE == PASS_FIRST) ok = idx < a.n_src;
+                    if constexpr (SMALL) ok = ok && batch < a.n_batch;
+                    if (ok) raw[g * M1 + ja] = src[idx];
                 } else {
                     raw[g * M1 + ja] = src[idx];
                 }
@@ -200,8 +230,8 @@ struct Geo {
 // canonical loads -> lazy limbs, plus the coset twist of a first pass.  The
 // twist factors are gathered four elements ahead of their use so that their
 // latency overlaps the multiplications of the previous four.
-template <int RA, int MODE, bool TWIST>
-__device__ __forceinline__ void unpack_tile(fe5 (&v)[16], const fe (&raw)[16], const PassArgs& a, uint32_t tx, int t)
+template <int RA, int MODE, bool TWIST, bool SMALL>
+__device__ __forceinline__ void unpack_tile(fe5 (&v)[16], const fe (&raw)[16], const PassArgs& a, uint64_t tile, int t)
 {
     using G = Geo<RA, MODE>;
     if constexpr (MODE == PASS_FIRST && TWIST) {
@@ -213,7 +243,8 @@ __device__ __forceinline__ void unpack_tile(fe5 (&v)[16], const fe (&raw)[16], c
             const int g = i / G::M1, ja = i % G::M1;
             const int q1 = t + TILE_THREADS * g;
             const int jb = q1 >> G::LOGC, c = q1 & (G::C - 1);
-            const uint64_t f = (uint64_t)tx * G::C + c;
+            uint64_t batch, f;
+            locate<RA, SMALL>(a, tile, c, batch, f);
             const uint64_t pre = f >> a.log_s;
             const uint64_t col = f & (((uint64_t)1 << a.log_s) - 1);
             const uint64_t base = (pre << (a.r + a.log_s)) + col;
@@ -296,8 +327,8 @@ __device__ __forceinline__ void round1_exchange(fe5 (&v)[16], fe5* lds, const tw
 // round 2 (radix 16 over jb), outgoing twiddle, store
 // NEXT_LAST: 0 = the next pass is not the last, 1 = it is and the twiddle is formed as hi*lo, 2 = it is
 // and the twiddle comes from the plane
-template <int RA, int MODE, int NEXT_LAST>
-__device__ __forceinline__ void round2_store(fe5 (&v)[16], const PassArgs& a, fe* __restrict__ dst, uint32_t tx,
+template <int RA, int MODE, int NEXT_LAST, bool SMALL>
+__device__ __forceinline__ void round2_store(fe5 (&v)[16], const PassArgs& a, uint64_t tile,
                                              const tw5* __restrict__ tw16, int t)
 {
     using G = Geo<RA, MODE>;
@@ -305,20 +336,25 @@ __device__ __forceinline__ void round2_store(fe5 (&v)[16], const PassArgs& a, fe
     // The store addresses are recomputed here from values the compiler cannot
     // tie to the load addresses of the start of the pass; otherwise it keeps 16
     // address pairs alive across both rounds and spills some of them.
-    asm volatile("" : "+v"(t), "+s"(tx));
+    asm volatile("" : "+v"(t), "+s"(tile));
     const int ka2 = t >> G::LOGC, c2 = t & (G::C - 1);
+    uint64_t batch, f;
+    locate<RA, SMALL>(a, tile, c2, batch, f);
+    fe* __restrict__ dst = a.dst + batch * a.dst_batch_stride;
+    bool live = true;                                      // a shared tile may reach past the end of the batch
+    if constexpr (SMALL) live = batch < a.n_batch;
     if constexpr (MODE == PASS_LAST) {
         ntt_dif_reg<4, 0>(v, tw16);
-        const uint64_t b = (uint64_t)tx * G::C + c2;
+        const uint64_t b = f;
         const uint32_t sh = a.log_n - a.r;
 #pragma unroll
         for (int kb = 0; kb < 16; kb++) {
             uint32_t k = ka2 + M1 * kb;
             asm volatile("" : "+v"(k));
-            dst[((uint64_t)k << sh) + b] = finish_lazy(v[brev_c(kb, 4)]);
+            const fe o = finish_lazy(v[brev_c(kb, 4)]);
+            if (live) dst[((uint64_t)k << sh) + b] = o;
         }
     } else {
-        const uint64_t f = (uint64_t)tx * G::C + c2;
         const uint32_t pre = (uint32_t)(f >> a.log_s);
         const uint64_t col = f & (((uint64_t)1 << a.log_s) - 1);
         const uint64_t base = ((uint64_t)pre << (a.r + a.log_s)) + col;
@@ -351,7 +387,8 @@ __device__ __forceinline__ void round2_store(fe5 (&v)[16], const PassArgs& a, fe
                     if (kb + 1 < 16) issue(kb + 1);
                     uint32_t k = ka2 + M1 * kb;
                     asm volatile("" : "+v"(k));
-                    dst[base + ((uint64_t)k << a.log_s)] = finish(mont_mul5_v(v[brev_c(kb, 4)], w[kb & 1]));
+                    const fe o = finish(mont_mul5_v(v[brev_c(kb, 4)], w[kb & 1]));
+                    if (live) dst[base + ((uint64_t)k << a.log_s)] = o;
                 }
             }
         } else if constexpr (NEXT_LAST == 1) {
@@ -379,7 +416,8 @@ __device__ __forceinline__ void round2_store(fe5 (&v)[16], const PassArgs& a, fe
                     uint32_t k = ka2 + M1 * kb;
                     asm volatile("" : "+v"(k));        // address formed here, not 16 at once up front
                     const fe5 w = mont_mul5_v(*(const fe5*)&wh[bt & 1][i], wl[bt & 1][i]);
-                    dst[base + ((uint64_t)k << a.log_s)] = finish(mont_mul5_v(v[brev_c(kb, 4)], w));
+                    const fe o = finish(mont_mul5_v(v[brev_c(kb, 4)], w));
+                    if (live) dst[base + ((uint64_t)k << a.log_s)] = o;
                 }
             }
         } else {
@@ -404,7 +442,8 @@ __device__ __forceinline__ void round2_store(fe5 (&v)[16], const PassArgs& a, fe
                     const int kb = bt * B + i;
                     uint32_t k = ka2 + M1 * kb;
                     asm volatile("" : "+v"(k));        // address formed here, not 16 at once up front
-                    dst[base + ((uint64_t)k << a.log_s)] = finish(mont_mul5_v(v[brev_c(kb, 4)], w[bt & 1][i]));
+                    const fe o = finish(mont_mul5_v(v[brev_c(kb, 4)], w[bt & 1][i]));
+                    if (live) dst[base + ((uint64_t)k << a.log_s)] = o;
                 }
             }
         }
@@ -445,7 +484,7 @@ hipError_t launch_ntt_plane(const PassArgs& a, int32_t* plane, hipStream_t s)
 // the lo table) and reduces its lazy outputs directly (finish_lazy).
 // One workgroup per tile; three workgroups are resident per CU (168 registers,
 // 48-52 KiB of LDS each) and hide one another's memory and barrier waits.
-template <int RA, int MODE, bool TWIST, int NEXT_LAST>
+template <int RA, int MODE, bool TWIST, int NEXT_LAST, bool SMALL>
 __global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) void ntt_pass_kernel(PassArgs a)
 {
     using G = Geo<RA, MODE>;
@@ -453,65 +492,73 @@ __global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(3,
     __shared__ tw5 s_tw256[256];
     const int t = threadIdx.x;
     const tw5* __restrict__ tw16 = a.tw16;
-    const uint32_t ltiles = a.log_n - 12;
     s_tw256[t] = a.tw256[t];
 
     const uint64_t tile = blockIdx.x;
-    const uint64_t batch = tile >> ltiles;
-    const uint32_t tx = (uint32_t)(tile & (((uint64_t)1 << ltiles) - 1));
     fe raw[16];
     fe5 v[16];
-    load_tile<RA, MODE>(raw, a, tile, t);
-    unpack_tile<RA, MODE, TWIST>(v, raw, a, tx, t);
+    load_tile<RA, MODE, SMALL>(raw, a, tile, t);
+    unpack_tile<RA, MODE, TWIST, SMALL>(v, raw, a, tile, t);
     lds_barrier();          // s_tw256 staged
     round1_exchange<RA, MODE>(v, lds, s_tw256, tw16, t);
-    round2_store<RA, MODE, NEXT_LAST>(v, a, a.dst + batch * a.dst_batch_stride, tx, tw16, t);
+    round2_store<RA, MODE, NEXT_LAST, SMALL>(v, a, tile, tw16, t);
 }
 
-template <int RA, int MODE, bool TWIST, int NEXT_LAST>
-static hipError_t launch_one(const PassArgs& a, uint32_t n_batch, hipStream_t s)
+template <int RA, int MODE, bool TWIST, int NEXT_LAST, bool SMALL>
+static hipError_t launch_one(const PassArgs& a, hipStream_t s)
 {
-    const uint64_t total = (((uint64_t)1 << a.log_n) / TILE_ELEMS) * n_batch;
+    const uint64_t total = ((((uint64_t)1 << a.log_n) * a.n_batch) + TILE_ELEMS - 1) / TILE_ELEMS;
+    if (total == 0) return hipSuccess;
     if (total > 0x7fffffffull) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((ntt_pass_kernel<RA, MODE, TWIST, NEXT_LAST>), dim3((uint32_t)total), dim3(TILE_THREADS), 0, s, a);
+    hipLaunchKernelGGL((ntt_pass_kernel<RA, MODE, TWIST, NEXT_LAST, SMALL>), dim3((uint32_t)total), dim3(TILE_THREADS), 0, s, a);
     return hipGetLastError();
 }
 
-template <int RA>
-static hipError_t launch_ra(const PassArgs& a, PassMode mode, bool twist, uint32_t n_batch, hipStream_t s)
+template <int RA, bool SMALL>
+static hipError_t launch_ra(const PassArgs& a, PassMode mode, bool twist, hipStream_t s)
 {
     const int nl = a.next_is_last ? (a.plane ? 2 : 1) : 0;
     switch (mode) {
     case PASS_FIRST:
-        if (twist) return nl == 2 ? launch_one<RA, PASS_FIRST, true, 2>(a, n_batch, s)
-                   : nl == 1      ? launch_one<RA, PASS_FIRST, true, 1>(a, n_batch, s)
-                                  : launch_one<RA, PASS_FIRST, true, 0>(a, n_batch, s);
-        return nl == 2 ? launch_one<RA, PASS_FIRST, false, 2>(a, n_batch, s)
-               : nl == 1 ? launch_one<RA, PASS_FIRST, false, 1>(a, n_batch, s)
-                         : launch_one<RA, PASS_FIRST, false, 0>(a, n_batch, s);
+        if (twist) return nl == 2 ? launch_one<RA, PASS_FIRST, true, 2, SMALL>(a, s)
+                   : nl == 1      ? launch_one<RA, PASS_FIRST, true, 1, SMALL>(a, s)
+                                  : launch_one<RA, PASS_FIRST, true, 0, SMALL>(a, s);
+        return nl == 2 ? launch_one<RA, PASS_FIRST, false, 2, SMALL>(a, s)
+               : nl == 1 ? launch_one<RA, PASS_FIRST, false, 1, SMALL>(a, s)
+                         : launch_one<RA, PASS_FIRST, false, 0, SMALL>(a, s);
     case PASS_MIDDLE:
-        return nl == 2 ? launch_one<RA, PASS_MIDDLE, false, 2>(a, n_batch, s)
-               : nl == 1 ? launch_one<RA, PASS_MIDDLE, false, 1>(a, n_batch, s)
-                         : launch_one<RA, PASS_MIDDLE, false, 0>(a, n_batch, s);
-    case PASS_LAST: return launch_one<RA, PASS_LAST, false, 0>(a, n_batch, s);
+        if constexpr (SMALL) return hipErrorInvalidValue;      // short transforms take two passes: no middle one
+        else return nl == 2 ? launch_one<RA, PASS_MIDDLE, false, 2, false>(a, s)
+                    : nl == 1 ? launch_one<RA, PASS_MIDDLE, false, 1, false>(a, s)
+                              : launch_one<RA, PASS_MIDDLE, false, 0, false>(a, s);
+    case PASS_LAST: return launch_one<RA, PASS_LAST, false, 0, SMALL>(a, s);
     }
     return hipErrorInvalidValue;
 }
 
-hipError_t launch_ntt_pass(const PassArgs& a, PassMode mode, bool twist, uint32_t n_batch, hipStream_t s)
+hipError_t launch_ntt_pass(const PassArgs& a_in, PassMode mode, bool twist, uint32_t n_batch, hipStream_t s)
 {
-    if (a.log_n < (uint32_t)PASS_MIN_LOG || a.log_n > 30) return hipErrorInvalidValue;
+    if (a_in.log_n < (uint32_t)PASS_MIN_LOG || a_in.log_n > 30) return hipErrorInvalidValue;
+    PassArgs a = a_in;
+    a.n_batch = n_batch;
+    if (a.log_n < 12) {                                        // several transforms share a 4096-element tile
+        switch (a.r) {
+        case 5: return launch_ra<1, true>(a, mode, twist, s);
+        case 6: return launch_ra<2, true>(a, mode, twist, s);
+        }
+        return hipErrorInvalidValue;
+    }
     switch (a.r) {
-    case 5: return launch_ra<1>(a, mode, twist, n_batch, s);
-    case 6: return launch_ra<2>(a, mode, twist, n_batch, s);
-    case 7: return launch_ra<3>(a, mode, twist, n_batch, s);
-    case 8: return launch_ra<4>(a, mode, twist, n_batch, s);
+    case 5: return launch_ra<1, false>(a, mode, twist, s);
+    case 6: return launch_ra<2, false>(a, mode, twist, s);
+    case 7: return launch_ra<3, false>(a, mode, twist, s);
+    case 8: return launch_ra<4, false>(a, mode, twist, s);
     }
     return hipErrorInvalidValue;
 }
 
 // ---------------------------------------------------------------------------
-// n <= 4096: the whole transform lives in one workgroup's LDS.
+// n < 1024: the whole transform lives in one workgroup's LDS.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(TILE_THREADS) void ntt_small_kernel(SmallArgs a)
 {

@@ -76,7 +76,8 @@ def test_ntt_2_24_full_size(ctx):
 
 
 def test_ntt_batch(ctx):
-    for log_n, cols in ((5, 7), (13, 5), (16, 3)):
+    # 2^10 and 2^11: several transforms share a 4096-element tile, the last tile reaching past the batch
+    for log_n, cols in ((5, 7), (13, 5), (16, 3), (10, 1), (10, 7), (10, 8), (11, 3), (11, 130)):
         n = 1 << log_n
         x = oc.splitmix(n * cols, 77 + log_n).reshape(cols, n, 2)
         out = ctx.ntt_batch(x)
@@ -139,6 +140,18 @@ def test_coset_lde_batch_columns(ctx):
     out = ctx.coset_lde_batch(c, n_out, G)
     for k in range(cols):
         assert np.array_equal(out[k], oc.coset_lde(c[k], n_out, G))
+
+
+@pytest.mark.parametrize("n_coeffs,n_out,cols", [(300, 1024, 5), (1024, 1024, 9), (1, 2048, 3), (2048, 2048, 2), (700, 2048, 131)])
+def test_coset_lde_batch_short_columns(ctx, n_coeffs, n_out, cols):
+    """Short columns (the local steps of a split transform, FRI-sized batches): transforms of 1024 and
+    2048 points share tiles."""
+    c = _edge_vector(cols * n_coeffs, n_out + cols).reshape(cols, n_coeffs, 2)
+    out = ctx.coset_lde_batch(c, n_out, G)
+    for k in range(cols):
+        assert np.array_equal(out[k], oc.coset_lde(np.ascontiguousarray(c[k]), n_out, G)), f"column {k}"
+    out1 = ctx.coset_lde_batch(c, n_out, 1)
+    assert np.array_equal(out1[cols - 1], oc.coset_lde(np.ascontiguousarray(c[cols - 1]), n_out, 1))
 
 
 def test_coset_lde_full_size_column(ctx):
