@@ -27,7 +27,10 @@
 // reference's polynomials coefficient for coefficient, and at the reference's
 // own size the proof is the reference algorithm's proof byte for byte.
 #pragma once
+#include <atomic>
 #include <chrono>
+#include <future>
+#include <thread>
 
 #include "stark_prover.hpp"
 
@@ -367,9 +370,25 @@ struct ScaledStark {
 
         // ---- trace columns with their randomizers (:237-253), interpolated (:260-275)
         std::vector<FieldElement> columns(R * n_rows);
-        for (size_t c = 0; c < T; c++) {
-            if (trace[c].size() != R) throw Panic("trace row has the wrong number of registers");
-            for (size_t s = 0; s < R; s++) columns[s * n_rows + c] = trace[c][s];
+        {
+            // rows to columns: every row is a heap object of its own, so this is a walk through memory;
+            // a few threads take a range of cycles each
+            const size_t workers = T >= ((size_t)1 << 16) ? 4 : 1;
+            std::vector<std::thread> pool;
+            std::vector<int> bad(workers, 0);
+            for (size_t w = 0; w < workers; w++)
+                pool.emplace_back([&, w] {
+                    for (size_t c = T * w / workers; c < T * (w + 1) / workers; c++) {
+                        if (trace[c].size() != R) {
+                            bad[w] = 1;
+                            return;
+                        }
+                        for (size_t s = 0; s < R; s++) columns[s * n_rows + c] = trace[c][s];
+                    }
+                });
+            for (auto& th : pool) th.join();
+            for (int b : bad)
+                if (b) throw Panic("trace row has the wrong number of registers");
         }
         {
             std::vector<uint8_t> bytes(17 * num_randomizers * R);
@@ -380,6 +399,12 @@ struct ScaledStark {
                     columns[s * n_rows + T + k] = FieldElement::sample(std::vector<uint8_t>(b, b + 17));
                 }
         }
+        // the randomizer polynomial's raw bytes (:344-353) are the next thing the random source yields: they are
+        // drawn on a helper thread while the device works on the trace (tens of megabytes for a long trace)
+        const size_t max_deg = max_degree(air);
+        const size_t n_random = 17 * (max_deg + 1);
+        if (random_staging.size() < n_random) random_staging.resize(n_random);
+        std::future<void> drawn = std::async(std::launch::async, [&] { rng(random_staging.data(), n_random); });
         DeviceVector trace_values(R * n_rows), tp(R * n_rows);
         trace_values.upload(columns);
         lap(tm.host);
@@ -439,7 +464,6 @@ struct ScaledStark {
         // ---- transition quotients (:309-341) by values on a coset of a subgroup that contains omicron: the
         // composition with omicron * x (:319-325) is the same column read omicron's place count further on
         std::vector<size_t> tq_bounds = transition_quotient_degree_bounds(air);
-        const size_t max_deg = max_degree(air);
         // the quotients have max_deg + 1 coefficients at most; their values are taken on a coset of that many
         // points (the omicron domain's size in the reference's own configuration), never fewer than the
         // omicron domain so that multiplying x by omicron stays a whole number of places
@@ -488,11 +512,9 @@ struct ScaledStark {
         // ---- randomizer polynomial (:344-360)
         DeviceVector randomizer(max_deg + 1), rz_codeword(n_fri);
         {
-            const size_t n_bytes = 17 * (max_deg + 1);
-            if (random_staging.size() < n_bytes) random_staging.resize(n_bytes);    // tens of megabytes, touched once
-            rng(random_staging.data(), n_bytes);
-            DeviceBuffer raw(n_bytes);
-            check(stark_copy_h2d(ctx, raw.p, random_staging.data(), n_bytes));
+            drawn.get();                                          // rethrows what the random source threw
+            DeviceBuffer raw(n_random);
+            check(stark_copy_h2d(ctx, raw.p, random_staging.data(), n_random));
             check(stark_sample_bytes_dev(ctx, (const uint8_t*)raw.p, 17, max_deg + 1, 1, randomizer.words()));
             check(stark_ctx_synchronize(ctx));
         }
@@ -647,9 +669,44 @@ struct ScaledStark {
         std::vector<size_t> tq_bounds = transition_quotient_degree_bounds(air);
         std::vector<size_t> bq_bounds = boundary_quotient_degree_bounds(randomized_trace_length, boundary);
         const starkf::HostField& F = host_field();
+        // The long evaluations first, side by side on a few threads: at every opened point the K constant
+        // polynomials (Horner over T - 1 coefficients) and the transition zeroifier as the product it is
+        // (:666, one factor per trace point).
+        std::vector<FieldElement> xs;
+        for (size_t idx : indices) xs.push_back(generator * omega.pow(idx));
+        std::vector<FieldElement> constant_values(indices.size() * K), tz_values(indices.size());
+        {
+            const size_t tasks = indices.size() * (K + 1);
+            std::atomic<size_t> next{0};
+            auto work = [&] {
+                for (size_t task = next++; task < tasks; task = next++) {
+                    const size_t i = task / (K + 1), k = task % (K + 1);
+                    const starkf::fe xm = F.to_mont(xs[i].raw());
+                    if (k < K) {
+                        starkf::fe acc{0, 0};
+                        const FieldElement* c = constants.data() + k * steps;
+                        for (size_t j = steps; j-- > 0;) acc = starkf::fe_add(starkf::mont_mul(acc, xm), c[j].raw());
+                        constant_values[i * K + k] = FieldElement::wrap(acc);
+                    } else {
+                        starkf::fe tz = F.one_m, w = F.one_m;
+                        const starkf::fe om = F.to_mont(omicron.raw());
+                        for (size_t j = 0; j + 1 < original_trace_length; j++) {
+                            tz = starkf::mont_mul(tz, starkf::fe_sub(xm, w));
+                            w = starkf::mont_mul(w, om);
+                        }
+                        tz_values[i] = FieldElement::wrap(F.from_mont(tz));
+                    }
+                }
+            };
+            const size_t workers = original_trace_length >= ((size_t)1 << 14) ? std::min<size_t>(8, tasks) : 1;
+            std::vector<std::thread> pool;
+            for (size_t w = 1; w < workers; w++) pool.emplace_back(work);
+            work();
+            for (auto& th : pool) th.join();
+        }
         for (size_t i = 0; i < indices.size(); i++) {                                        // :589-719
             size_t current_index = indices[i];
-            FieldElement xcur = generator * omega.pow(current_index);
+            FieldElement xcur = xs[i];
             size_t next_index = (current_index + expansion_factor) % fri.domain_length;
             FieldElement xnext = xcur * omicron;
             std::vector<FieldElement> point{xcur}, next_trace;
@@ -658,21 +715,8 @@ struct ScaledStark {
                 next_trace.push_back(leafs[s].at(next_index) * zeroifiers[s].eval(xnext) + interpolants[s].eval(xnext));
             }
             point.insert(point.end(), next_trace.begin(), next_trace.end());
-            const starkf::fe xm = F.to_mont(xcur.raw());
-            for (size_t k = 0; k < K; k++) {                   // Horner, highest coefficient first
-                starkf::fe acc{0, 0};
-                const FieldElement* c = constants.data() + k * steps;
-                for (size_t j = steps; j-- > 0;) acc = starkf::fe_add(starkf::mont_mul(acc, xm), c[j].raw());
-                point.push_back(FieldElement::wrap(acc));
-            }
-            // the transition zeroifier at x as the product it is (:666): one factor per trace point
-            starkf::fe tz = F.one_m, w = F.one_m;
-            const starkf::fe om = F.to_mont(omicron.raw());
-            for (size_t j = 0; j + 1 < original_trace_length; j++) {
-                tz = starkf::mont_mul(tz, starkf::fe_sub(xm, w));
-                w = starkf::mont_mul(w, om);
-            }
-            FieldElement tz_inv = FieldElement::wrap(F.from_mont(tz)).inverse();
+            for (size_t k = 0; k < K; k++) point.push_back(constant_values[i * K + k]);
+            FieldElement tz_inv = tz_values[i].inverse();
             std::vector<FieldElement> terms{randomizer.at(current_index)};
             for (size_t s = 0; s < air.size(); s++) {
                 FieldElement qv = air[s].eval(point) * tz_inv;
