@@ -60,7 +60,10 @@ def ntt_roofline(pmc, source, key, n, avg_launch_ms, kernel):
         # SQ_INSTS_VALU_INT64) against one such instruction per SIMD per 4 cycles
         r["valu_int64"] = {"achieved": round(i64, 1), "peak": VALU_INT64_PEAK_GINSTR_S, "unit": "Gwave-instr/s",
                            "frac": round(i64 / VALU_INT64_PEAK_GINSTR_S, 4),
-                           "all_valu_wave_instr_per_launch": int(e["valu_wave_instr_per_launch"])}
+                           "all_valu_wave_instr_per_launch": int(e["valu_wave_instr_per_launch"]),
+                           # SQ_WAIT_INST_ANY / SQ_WAIT_ANY against SQ_WAVE_CYCLES: with about three waves per SIMD,
+                           # a wave that issues a third of the time means a saturated issue port
+                           "wave_cycles_split": e.get("wave_cycles_split")}
     return r
 
 

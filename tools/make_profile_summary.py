@@ -113,10 +113,20 @@ for wl, reps in WORKLOADS.items():
         entry["int64_wave_instr_per_launch"] = sum(sum(v[k]["SQ_INSTS_VALU_INT64"]) for k in passes) / n_l
         entry["valu_wave_instr_per_launch"] = sum(sum(v[k]["SQ_INSTS_VALU"]) for k in passes) / n_l
         entry["pass_launches_profiled"] = n_l
+        # where a resident wave's cycles go (guide: WAIT_ANY = parked on s_waitcnt or a barrier, WAIT_INST_ANY =
+        # ready but not issued because the pipe is taken, the rest = issuing; the three are disjoint)
+        wc = sum(sum(v[k]["SQ_WAVE_CYCLES"]) for k in passes)
+        wa = sum(sum(v[k]["SQ_WAIT_ANY"]) for k in passes)
+        wi = sum(sum(v[k]["SQ_WAIT_INST_ANY"]) for k in passes)
+        entry["wave_cycles_split"] = {"issuing": round(1 - (wa + wi) / wc, 4), "issue_stall": round(wi / wc, 4),
+                                      "waitcnt_or_barrier": round(wa / wc, 4)}
         n = 1 << int(wl[3:])
         w("  mean over the %d pass launches: HBM-side traffic %.1f MB per launch (algorithmic 32 B x 2^%s = %.1f MB), "
           "%.0f 64-bit-class of %.0f VALU wave-instructions" % (n_l, tr / 1e6, wl[3:], 32 * n / 1e6,
                                                                  entry["int64_wave_instr_per_launch"], entry["valu_wave_instr_per_launch"]))
+        w("  a resident wave's cycles: %.0f %% issuing, %.0f %% ready but held back by a busy pipe (SQ_WAIT_INST_ANY), "
+          "%.0f %% parked on s_waitcnt or a barrier (SQ_WAIT_ANY)" % tuple(100 * entry["wave_cycles_split"][k] for k in
+                                                                            ("issuing", "issue_stall", "waitcnt_or_barrier")))
     else:
         entry["traffic_bytes_per_call"] = (tot_read + tot_write) / reps
         entry["valu_wave_instr_per_call"] = tot_valu / reps
