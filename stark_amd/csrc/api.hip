@@ -17,6 +17,7 @@
 #include "../../include/stark_hip.h"
 #include "field_host.hpp"
 #include "internal.hpp"
+#include "tw16_tables.hpp"
 
 using namespace starkf;
 using starkh::digest;
@@ -49,8 +50,7 @@ namespace {
 struct NttTables {
     uint32_t log_n = 0, h = 0;
     std::vector<uint32_t> radices;   // empty for the single-workgroup path
-    tw5* tw16 = nullptr;             // multi-pass path: five-limb Montgomery forms (2^156)
-    tw5* tw256 = nullptr;
+    tw5* tw256 = nullptr;            // multi-pass path: five-limb Montgomery forms (2^156)
     tw5* hi = nullptr;
     tw5* lo = nullptr;               // omega^i, i < 2^h; times n^-1 for the inverse
     int32_t* plane = nullptr;        // outgoing twiddles of the pass before the last, 5 limbs per element (built on first use)
@@ -292,6 +292,25 @@ static std::vector<tw5> powers_5(const HostField& F, fe x, size_t count, fe firs
     return v;
 }
 
+// Does row [inverse] of the literal table TW16C hold the tabulated forms (limb k of w16^e * 2^(26 i + 52))
+// of the powers of w16?
+static bool tw16_literals_match(const HostField& F, fe w16, bool inverse)
+{
+    fe cur{1, 0};
+    for (int e = 0; e < 8; e++) {
+        fe sh = cur;
+        for (int b = 0; b < 52; b++) sh = fe_add(sh, sh);
+        for (int i = 0; i < 5; i++) {
+            const fe5 l = unpack5(sh);
+            for (int k = 0; k < 5; k++)
+                if (TW16C[inverse ? 1 : 0][e].l[k][i] != l.l[k]) return false;
+            for (int b = 0; b < 26; b++) sh = fe_add(sh, sh);
+        }
+        cur = F.mul(cur, w16);
+    }
+    return true;
+}
+
 // Sizes up to this keep a twiddle plane (20 bytes per element and direction: 1.3 GB at 2^26).
 constexpr uint32_t PLANE_MAX_LOG = 26;
 
@@ -307,9 +326,9 @@ static std::vector<uint32_t> plan_radices(uint32_t log_n)
 
 static void free_ntt_tables(NttTables& t)
 {
-    (void)hipFree(t.tw16); (void)hipFree(t.tw256); (void)hipFree(t.hi); (void)hipFree(t.lo);
+    (void)hipFree(t.tw256); (void)hipFree(t.hi); (void)hipFree(t.lo);
     (void)hipFree(t.small); (void)hipFree(t.plane);
-    t.tw16 = t.tw256 = t.hi = t.lo = nullptr;
+    t.tw256 = t.hi = t.lo = nullptr;
     t.small = nullptr;
     t.plane = nullptr;
 }
@@ -339,8 +358,11 @@ static int32_t get_ntt_tables(stark_ctx* ctx, uint32_t log_n, bool inverse, cons
         fe w16 = F.pow(omega, (u128)1 << (log_n - 4));
         fe w256 = F.pow(omega, (u128)1 << (log_n - 8));
         fe w_hi = F.pow(omega, (u128)1 << t.h);
-        rc = upload(ctx, powers_5(F, w16, 8), &t.tw16);
-        if (rc == STARK_OK) rc = upload(ctx, powers_5(F, w256, 256), &t.tw256);
+        // the kernels carry the powers of the 16th root as literals (tw16_tables.hpp); they must be the
+        // powers of THIS root
+        if (!tw16_literals_match(F, w16, inverse))
+            return fail(STARK_EARG, "the compiled-in 16th-root table does not match primitive_nth_root");
+        rc = upload(ctx, powers_5(F, w256, 256), &t.tw256);
         if (rc == STARK_OK) rc = upload(ctx, powers_5(F, w_hi, (size_t)1 << (log_n - t.h)), &t.hi);
         // ntt.rs:36-39: the inverse's n^-1 rides on the lo table, which enters exactly one product per
         // element (the outgoing twiddle of the pass before the last); the last pass multiplies nothing
@@ -447,7 +469,7 @@ static int32_t run_ntt(stark_ctx* ctx, const fe* src, size_t src_stride, size_t 
         for (size_t q = 0; q < P; q++) {
             log_s -= t->radices[q];
             PassArgs a{};
-            a.tw16 = t->tw16;
+            a.inverse = inverse ? 1 : 0;
             a.tw256 = t->tw256;
             a.hi = t->hi;
             a.lo = t->lo;

@@ -14,7 +14,10 @@
 //
 // mont_mul5(a, w) returns a*w*2^-156 mod p up to a multiple of p, in
 // (-2^107, p + 2^107], for ANY int32 limbs of a and a normalised w (limbs in
-// [0, 2^26), value < p).  Six digit steps (R = 2^156) rather than five make the
+// [0, 2^26), value < p).  With PLUS_P = false the final "+ p" is left out and the
+// result lies in (-p - 2^107, 2^107]: as good an operand for further lazy sums and
+// products, two instructions cheaper, but not for pack_fast / finish, which expect a
+// non-negative value.  Six digit steps (R = 2^156) rather than five make the
 // result nearly canonical whatever the laziness of a.  Twiddles are stored as
 // w*2^156 mod p (struct tw5).  pack_canonical() finishes the reduction.
 #pragma once
@@ -80,7 +83,7 @@ STARK_HD fe5 sub5(const fe5& a, const fe5& b)
 // l4 = small signed carry + P4; value in (-2^107, p + 2^107].
 STARK_HD int64_t mad64(int32_t a, int32_t b, int64_t c) { return (int64_t)a * (int64_t)b + c; }
 
-template <class W>
+template <bool PLUS_P = true, class W>
 STARK_HD fe5 mont_mul5(const fe5& a, const W& w)
 {
     const int32_t a0 = a.l[0], a1 = a.l[1], a2 = a.l[2], a3 = a.l[3], a4 = a.l[4];
@@ -128,7 +131,7 @@ STARK_HD fe5 mont_mul5(const fe5& a, const W& w)
     t = mad64(a3, w3, t);
     t = mad64(a4, w2, t);
     t = mad64(m2, NP4, t);
-    r.l[0] = ((int32_t)t & LIMB_MASK) + 1;            // + p, low digit
+    r.l[0] = ((int32_t)t & LIMB_MASK) + (PLUS_P ? 1 : 0);   // + p, low digit
     t >>= LIMB_BITS;
     t = mad64(a3, w4, t);
     t = mad64(a4, w3, t);
@@ -142,7 +145,7 @@ STARK_HD fe5 mont_mul5(const fe5& a, const W& w)
     t = mad64(m5, NP4, t);
     r.l[3] = (int32_t)t & LIMB_MASK;
     t >>= LIMB_BITS;
-    r.l[4] = (int32_t)t + P4;                          // + p, high digit
+    r.l[4] = (int32_t)t + (PLUS_P ? P4 : 0);          // + p, high digit
     return r;
 }
 
@@ -210,11 +213,10 @@ STARK_HD fe5 mont_mul5(const fe5& a, const W& w)
     "v_ashrrev_i64 " F5_ACC ", 26, " F5_ACC "\n\t"                \
     "v_mad_i64_i32 " F5_ACC ", vcc, %[m1], %[np4], " F5_ACC "\n\t" \
     "v_and_b32 %[r3], 0x3ffffff, " F5_ACC_LO "\n\t"                        \
-    "v_ashrrev_i64 " F5_ACC ", 26, " F5_ACC "\n\t"                \
-    "v_mov_b32 %[r4], " F5_ACC_LO
+    "v_alignbit_b32 %[r4], " F5_ACC_HI ", " F5_ACC_LO ", 26"
 
 #define STARK_MM5_DEFINE(NAME, WS)                                                                            \
-    template <class W>                                                                                        \
+    template <bool PLUS_P = true, class W>                                                                    \
     __device__ __forceinline__ fe5 NAME(const fe5& a, const W& w)                                             \
     {                                                                                                         \
         int32_t r0, r1, r2, r3, r4, m0, m1, m2, m3;                                                           \
@@ -226,19 +228,120 @@ STARK_HD fe5 mont_mul5(const fe5& a, const W& w)
               [np4] "s"(-P4)                                                                                  \
             : "vcc", F5_ACC_LO, F5_ACC_HI);                                                                         \
         fe5 r;                                                                                                \
-        r.l[0] = r0 + 1;                                                                                      \
+        r.l[0] = PLUS_P ? r0 + 1 : r0;                                                                        \
         r.l[1] = r1;                                                                                          \
         r.l[2] = r2;                                                                                          \
         r.l[3] = r3;                                                                                          \
-        r.l[4] = r4 + P4;                                                                                     \
+        r.l[4] = PLUS_P ? r4 + P4 : r4;                                                                       \
         return r;                                                                                             \
     }
 STARK_MM5_DEFINE(mont_mul5_v, "v")   // twiddle limbs in vector registers
 STARK_MM5_DEFINE(mont_mul5_s, "s")   // twiddle limbs wave-uniform, in scalar registers
 #undef STARK_MM5_DEFINE
 #else
-template <class W> STARK_HD fe5 mont_mul5_v(const fe5& a, const W& w) { return mont_mul5(a, w); }
-template <class W> STARK_HD fe5 mont_mul5_s(const fe5& a, const W& w) { return mont_mul5(a, w); }
+template <bool PLUS_P = true, class W> STARK_HD fe5 mont_mul5_v(const fe5& a, const W& w) { return mont_mul5<PLUS_P>(a, w); }
+template <bool PLUS_P = true, class W> STARK_HD fe5 mont_mul5_s(const fe5& a, const W& w) { return mont_mul5<PLUS_P>(a, w); }
+#endif
+
+// A wave-uniform constant multiplier w, tabulated against every limb position of the other operand:
+// l[k][i] is limb k of (w * 2^(26 i + 52) mod p), normalised.  With it a * w is the sum over i of
+// a_i * (row i): 25 multiply-adds that fill only the five low columns, so two Montgomery digit steps
+// (instead of six) and six digit extractions (instead of ten) bring the result into range.
+struct alignas(16) tw25 {
+    int32_t l[5][5];
+    int32_t pad[3];
+};
+
+// a * w (w given as its tw25 table), same contract as mont_mul5's result: value = a * w mod p up to a
+// multiple of p, in (-2^110, p + 2^110) for ANY int32 limbs of a; l0 in [1, 2^26], l1..l3 in [0, 2^26),
+// l4 = small signed carry + P4.  PLUS_P = false: without the final "+ p", in (-p - 2^110, 2^110).
+template <bool PLUS_P = true>
+STARK_HD fe5 mont_mul5_c_ref(const fe5& a, const tw25& w)
+{
+    const int32_t NP4 = -P4;
+    int64_t t = 0;
+    int32_t m0, m1;
+    fe5 r;
+#pragma unroll
+    for (int i = 0; i < 5; i++) t = mad64(a.l[i], w.l[0][i], t);
+    m0 = (int32_t)t & LIMB_MASK;
+    t >>= LIMB_BITS;
+#pragma unroll
+    for (int i = 0; i < 5; i++) t = mad64(a.l[i], w.l[1][i], t);
+    m1 = (int32_t)t & LIMB_MASK;
+    t >>= LIMB_BITS;
+#pragma unroll
+    for (int i = 0; i < 5; i++) t = mad64(a.l[i], w.l[2][i], t);
+    r.l[0] = ((int32_t)t & LIMB_MASK) + (PLUS_P ? 1 : 0);
+    t >>= LIMB_BITS;
+#pragma unroll
+    for (int i = 0; i < 5; i++) t = mad64(a.l[i], w.l[3][i], t);
+    r.l[1] = (int32_t)t & LIMB_MASK;
+    t >>= LIMB_BITS;
+#pragma unroll
+    for (int i = 0; i < 5; i++) t = mad64(a.l[i], w.l[4][i], t);
+    t = mad64(m0, NP4, t);
+    r.l[2] = (int32_t)t & LIMB_MASK;
+    t >>= LIMB_BITS;
+    t = mad64(m1, NP4, t);
+    r.l[3] = (int32_t)t & LIMB_MASK;
+    t >>= LIMB_BITS;
+    r.l[4] = (int32_t)t + (PLUS_P ? P4 : 0);
+    return r;
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// Device form: one asm block per column (the compiler would otherwise re-associate the chain into
+// "sum the products, then add the carry"); the digit extraction between the blocks is plain C++.
+// The table limbs are wave-uniform and sit in scalar registers; VOP3 reads one scalar operand.
+#define STARK_MM5C_COL(T, K)                                                                                  \
+    asm("v_mad_i64_i32 %[t], vcc, %[a0], %[w0], %[t]\n\t"                                                     \
+        "v_mad_i64_i32 %[t], vcc, %[a1], %[w1], %[t]\n\t"                                                     \
+        "v_mad_i64_i32 %[t], vcc, %[a2], %[w2], %[t]\n\t"                                                     \
+        "v_mad_i64_i32 %[t], vcc, %[a3], %[w3], %[t]\n\t"                                                     \
+        "v_mad_i64_i32 %[t], vcc, %[a4], %[w4], %[t]"                                                         \
+        : [t] "+v"(T)                                                                                         \
+        : [a0] "v"(a.l[0]), [a1] "v"(a.l[1]), [a2] "v"(a.l[2]), [a3] "v"(a.l[3]), [a4] "v"(a.l[4]),           \
+          [w0] "s"(w.l[K][0]), [w1] "s"(w.l[K][1]), [w2] "s"(w.l[K][2]), [w3] "s"(w.l[K][3]), [w4] "s"(w.l[K][4]) \
+        : "vcc")
+template <bool PLUS_P = true>
+__device__ __forceinline__ fe5 mont_mul5_c(const fe5& a, const tw25& w)
+{
+    int64_t t;
+    int32_t m0, m1;
+    fe5 r;
+    asm("v_mad_i64_i32 %[t], vcc, %[a0], %[w0], 0\n\t"
+        "v_mad_i64_i32 %[t], vcc, %[a1], %[w1], %[t]\n\t"
+        "v_mad_i64_i32 %[t], vcc, %[a2], %[w2], %[t]\n\t"
+        "v_mad_i64_i32 %[t], vcc, %[a3], %[w3], %[t]\n\t"
+        "v_mad_i64_i32 %[t], vcc, %[a4], %[w4], %[t]"
+        : [t] "=&v"(t)
+        : [a0] "v"(a.l[0]), [a1] "v"(a.l[1]), [a2] "v"(a.l[2]), [a3] "v"(a.l[3]), [a4] "v"(a.l[4]),
+          [w0] "s"(w.l[0][0]), [w1] "s"(w.l[0][1]), [w2] "s"(w.l[0][2]), [w3] "s"(w.l[0][3]), [w4] "s"(w.l[0][4])
+        : "vcc");
+    m0 = (int32_t)t & LIMB_MASK;
+    t >>= LIMB_BITS;
+    STARK_MM5C_COL(t, 1);
+    m1 = (int32_t)t & LIMB_MASK;
+    t >>= LIMB_BITS;
+    STARK_MM5C_COL(t, 2);
+    r.l[0] = ((int32_t)t & LIMB_MASK) + (PLUS_P ? 1 : 0);
+    t >>= LIMB_BITS;
+    STARK_MM5C_COL(t, 3);
+    r.l[1] = (int32_t)t & LIMB_MASK;
+    t >>= LIMB_BITS;
+    STARK_MM5C_COL(t, 4);
+    asm("v_mad_i64_i32 %[t], vcc, %[m], %[np4], %[t]" : [t] "+v"(t) : [m] "v"(m0), [np4] "s"(-P4) : "vcc");
+    r.l[2] = (int32_t)t & LIMB_MASK;
+    t >>= LIMB_BITS;
+    asm("v_mad_i64_i32 %[t], vcc, %[m], %[np4], %[t]" : [t] "+v"(t) : [m] "v"(m1), [np4] "s"(-P4) : "vcc");
+    r.l[3] = (int32_t)t & LIMB_MASK;
+    r.l[4] = (int32_t)(t >> LIMB_BITS) + (PLUS_P ? P4 : 0);
+    return r;
+}
+#undef STARK_MM5C_COL
+#else
+template <bool PLUS_P = true> STARK_HD fe5 mont_mul5_c(const fe5& a, const tw25& w) { return mont_mul5_c_ref<PLUS_P>(a, w); }
 #endif
 
 // Exact reduction of any limb vector with |value| < 2^150 into [0, p); the slow

@@ -27,7 +27,6 @@ constexpr int MAX_PASSES = 4;
 struct PassArgs {
     const fe* src;
     fe* dst;
-    const tw5* tw16;       // omega_16^i, i<8
     const tw5* tw256;      // omega_256^i, i<256
     const tw5* hi;         // omega_n^(i << h), i < n >> h
     const tw5* lo;         // omega_n^i, i < 2^h (times n^-1 for the inverse transform)
@@ -45,6 +44,7 @@ struct PassArgs {
     uint32_t nprev;        // q
     uint32_t rprev[MAX_PASSES];   // log2 R_u, u < q
     uint32_t n_batch;             // transforms in the launch (set by launch_ntt_pass)
+    uint32_t inverse;             // 1: the butterfly constants are those of the inverse root (ntt.rs:19)
     // Pass before the last only: its outgoing twiddle omega_n^(j_next * K) has all of n as exponent
     // range.  If set, plane[5 i .. 5 i + 4] holds the five limbs of the twiddle of output element i
     // (same index as dst); otherwise the kernel multiplies hi and lo entries together per element.

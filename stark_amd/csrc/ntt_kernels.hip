@@ -16,6 +16,7 @@
 
 #include "field5.hpp"
 #include "internal.hpp"
+#include "tw16_tables.hpp"
 
 namespace starkk {
 
@@ -31,10 +32,11 @@ __device__ __forceinline__ constexpr int brev_c(int k, int bits)
 // In-register decimation-in-frequency transform of M = 2^LOGM lazy elements at
 // v[BASE .. BASE+M): natural order in, bit-reversed order out (output k sits in
 // register BASE + brev(k)).  Adds and subtracts are carry-free limb operations;
-// only the twiddle products reduce.  tw16[i] = w_16^i (Montgomery form, 2^156);
-// the index is a compile-time constant after unrolling, so the loads are scalar.
-template <int LOGM, int BASE>
-__device__ __forceinline__ void ntt_dif_reg(fe5 (&v)[16], const tw5* __restrict__ tw16)
+// only the twiddle products reduce.  The multipliers are powers of the 16th root of unity (of its
+// inverse when INV), constants of the field: the exponent is known after unrolling, so each product
+// reads its tabulated multiplier (TW16C) as instruction literals.
+template <int LOGM, int BASE, bool INV>
+__device__ __forceinline__ void ntt_dif_reg(fe5 (&v)[16])
 {
     constexpr int M = 1 << LOGM;
 #pragma unroll
@@ -50,23 +52,23 @@ __device__ __forceinline__ void ntt_dif_reg(fe5 (&v)[16], const tw5* __restrict_
                 v[BASE + s + j] = add5(a, b);
                 const fe5 d = sub5(a, b);
                 const int e = j * (16 / len);
-                v[BASE + s + j + half] = (e == 0) ? d : mont_mul5_s(d, tw16[e]);
+                v[BASE + s + j + half] = (e == 0) ? d : mont_mul5_c<false>(d, TW16C[INV ? 1 : 0][e]);
             }
         }
     }
 }
 
-template <int LOGM, int G>
+template <int LOGM, int G, bool INV>
 struct RoundOne {
-    __device__ __forceinline__ static void run(fe5 (&v)[16], const tw5* __restrict__ tw16)
+    __device__ __forceinline__ static void run(fe5 (&v)[16])
     {
-        ntt_dif_reg<LOGM, (G - 1) * (1 << LOGM)>(v, tw16);
-        RoundOne<LOGM, G - 1>::run(v, tw16);
+        ntt_dif_reg<LOGM, (G - 1) * (1 << LOGM), INV>(v);
+        RoundOne<LOGM, G - 1, INV>::run(v);
     }
 };
-template <int LOGM>
-struct RoundOne<LOGM, 0> {
-    __device__ __forceinline__ static void run(fe5 (&)[16], const tw5* __restrict__) {}
+template <int LOGM, bool INV>
+struct RoundOne<LOGM, 0, INV> {
+    __device__ __forceinline__ static void run(fe5 (&)[16]) {}
 };
 
 // memory prefix (k_0 most significant) -> K = k_0 + R_0 k_1 + ...
@@ -287,12 +289,11 @@ __device__ __forceinline__ void unpack_tile(fe5 (&v)[16], const fe (&raw)[16], c
 // A thread's 16 inputs all have ka = t >> LOGC, so waves 0-1 collect theirs in
 // phase 0 and waves 2-3 in phase 1.  Ends with every thread's LDS reads issued
 // and waited for, but NOT with a barrier.
-template <int RA, int MODE>
-__device__ __forceinline__ void round1_exchange(fe5 (&v)[16], fe5* lds, const tw5* s_tw256, const tw5* __restrict__ tw16,
-                                                int t)
+template <int RA, int MODE, bool INV>
+__device__ __forceinline__ void round1_exchange(fe5 (&v)[16], fe5* lds, const tw5* s_tw256, int t)
 {
     using G = Geo<RA, MODE>;
-    RoundOne<RA, G::G1>::run(v, tw16);
+    RoundOne<RA, G::G1, INV>::run(v);
     const int ka2 = t >> G::LOGC, c2 = t & (G::C - 1);
     const int my_phase = ka2 / G::KA_HALF;
     fe5 rcv[16];
@@ -311,7 +312,7 @@ __device__ __forceinline__ void round1_exchange(fe5 (&v)[16], fe5* lds, const tw
             for (int kh = 0; kh < G::KA_HALF; kh++) {
                 const int ka = ph * G::KA_HALF + kh;
                 const int reg = g * G::M1 + brev_c(ka, RA);
-                lds[(kh * 16 + jb) * G::PITCH + c] = mont_mul5_v(v[reg], s_tw256[(jb * ka) << G::TWSHIFT]);
+                lds[(kh * 16 + jb) * G::PITCH + c] = mont_mul5_v<false>(v[reg], s_tw256[(jb * ka) << G::TWSHIFT]);
             }
         }
         lds_barrier();
@@ -327,9 +328,8 @@ __device__ __forceinline__ void round1_exchange(fe5 (&v)[16], fe5* lds, const tw
 // round 2 (radix 16 over jb), outgoing twiddle, store
 // NEXT_LAST: 0 = the next pass is not the last, 1 = it is and the twiddle is formed as hi*lo, 2 = it is
 // and the twiddle comes from the plane
-template <int RA, int MODE, int NEXT_LAST, bool SMALL>
-__device__ __forceinline__ void round2_store(fe5 (&v)[16], const PassArgs& a, uint64_t tile,
-                                             const tw5* __restrict__ tw16, int t)
+template <int RA, int MODE, int NEXT_LAST, bool SMALL, bool INV>
+__device__ __forceinline__ void round2_store(fe5 (&v)[16], const PassArgs& a, uint64_t tile, int t)
 {
     using G = Geo<RA, MODE>;
     constexpr int M1 = G::M1;
@@ -344,7 +344,7 @@ __device__ __forceinline__ void round2_store(fe5 (&v)[16], const PassArgs& a, ui
     bool live = true;                                      // a shared tile may reach past the end of the batch
     if constexpr (SMALL) live = batch < a.n_batch;
     if constexpr (MODE == PASS_LAST) {
-        ntt_dif_reg<4, 0>(v, tw16);
+        ntt_dif_reg<4, 0, INV>(v);
         const uint64_t b = f;
         const uint32_t sh = a.log_n - a.r;
 #pragma unroll
@@ -380,7 +380,7 @@ __device__ __forceinline__ void round2_store(fe5 (&v)[16], const PassArgs& a, ui
                     asm volatile("" : "+v"(k));
                     w[kb & 1] = *(const fe5*)(plane + 5 * (base + ((uint64_t)k << a.log_s)));
                 };
-                ntt_dif_reg<4, 0>(v, tw16);
+                ntt_dif_reg<4, 0, INV>(v);
                 issue(0);
 #pragma clang loop unroll(full)
                 for (int kb = 0; kb < 16; kb++) {
@@ -405,7 +405,7 @@ __device__ __forceinline__ void round2_store(fe5 (&v)[16], const PassArgs& a, ui
                 }
             };
             // (two tables: the first batch waits until the butterflies have released their registers)
-            ntt_dif_reg<4, 0>(v, tw16);
+            ntt_dif_reg<4, 0, INV>(v);
             issue(0);
 #pragma clang loop unroll(full)
             for (int bt = 0; bt < 16 / B; bt++) {
@@ -433,7 +433,7 @@ __device__ __forceinline__ void round2_store(fe5 (&v)[16], const PassArgs& a, ui
                 }
             };
             issue(0);
-            ntt_dif_reg<4, 0>(v, tw16);
+            ntt_dif_reg<4, 0, INV>(v);
 #pragma clang loop unroll(full)
             for (int bt = 0; bt < 16 / B; bt++) {
                 if (bt + 1 < 16 / B) issue(bt + 1);
@@ -484,14 +484,13 @@ hipError_t launch_ntt_plane(const PassArgs& a, int32_t* plane, hipStream_t s)
 // the lo table) and reduces its lazy outputs directly (finish_lazy).
 // One workgroup per tile; three workgroups are resident per CU (168 registers,
 // 48-52 KiB of LDS each) and hide one another's memory and barrier waits.
-template <int RA, int MODE, bool TWIST, int NEXT_LAST, bool SMALL>
+template <int RA, int MODE, bool TWIST, int NEXT_LAST, bool SMALL, bool INV>
 __global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) void ntt_pass_kernel(PassArgs a)
 {
     using G = Geo<RA, MODE>;
     __shared__ fe5 lds[G::LDS_ELEMS];
     __shared__ tw5 s_tw256[256];
     const int t = threadIdx.x;
-    const tw5* __restrict__ tw16 = a.tw16;
     s_tw256[t] = a.tw256[t];
 
     const uint64_t tile = blockIdx.x;
@@ -500,18 +499,30 @@ __global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(3,
     load_tile<RA, MODE, SMALL>(raw, a, tile, t);
     unpack_tile<RA, MODE, TWIST, SMALL>(v, raw, a, tile, t);
     lds_barrier();          // s_tw256 staged
-    round1_exchange<RA, MODE>(v, lds, s_tw256, tw16, t);
-    round2_store<RA, MODE, NEXT_LAST, SMALL>(v, a, tile, tw16, t);
+    round1_exchange<RA, MODE, INV>(v, lds, s_tw256, t);
+    round2_store<RA, MODE, NEXT_LAST, SMALL, INV>(v, a, tile, t);
+}
+
+template <int RA, int MODE, bool TWIST, int NEXT_LAST, bool SMALL, bool INV>
+static hipError_t launch_dir(const PassArgs& a, hipStream_t s)
+{
+    const uint64_t total = ((((uint64_t)1 << a.log_n) * a.n_batch) + TILE_ELEMS - 1) / TILE_ELEMS;
+    if (total == 0) return hipSuccess;
+    if (total > 0x7fffffffull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((ntt_pass_kernel<RA, MODE, TWIST, NEXT_LAST, SMALL, INV>), dim3((uint32_t)total), dim3(TILE_THREADS), 0, s, a);
+    return hipGetLastError();
 }
 
 template <int RA, int MODE, bool TWIST, int NEXT_LAST, bool SMALL>
 static hipError_t launch_one(const PassArgs& a, hipStream_t s)
 {
-    const uint64_t total = ((((uint64_t)1 << a.log_n) * a.n_batch) + TILE_ELEMS - 1) / TILE_ELEMS;
-    if (total == 0) return hipSuccess;
-    if (total > 0x7fffffffull) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((ntt_pass_kernel<RA, MODE, TWIST, NEXT_LAST, SMALL>), dim3((uint32_t)total), dim3(TILE_THREADS), 0, s, a);
-    return hipGetLastError();
+    // the butterfly constants are those of the forward root or of its inverse; a coset twist only
+    // ever precedes a forward transform
+    if (a.inverse) {
+        if constexpr (TWIST) return hipErrorInvalidValue;
+        else return launch_dir<RA, MODE, TWIST, NEXT_LAST, SMALL, true>(a, s);
+    }
+    return launch_dir<RA, MODE, TWIST, NEXT_LAST, SMALL, false>(a, s);
 }
 
 template <int RA, bool SMALL>
