@@ -29,6 +29,9 @@ VALU_INT64_PEAK_GINSTR_S = 1024 * 2.4 / 4
 PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc.json")
 
 
+N_SIMD = 256 * 4                 # CUs x SIMDs per CU
+
+
 def load_pmc():
     """Counter figures of the committed profile (profiles/r02_pmc.json, written by
     tools/make_profile_summary.py from rocprofv3 --pmc passes).  They describe the kernels as they were
@@ -64,6 +67,16 @@ def ntt_roofline(pmc, source, key, n, avg_launch_ms, kernel):
                            # SQ_WAIT_INST_ANY / SQ_WAIT_ANY against SQ_WAVE_CYCLES: with about three waves per SIMD,
                            # a wave that issues a third of the time means a saturated issue port
                            "wave_cycles_split": e.get("wave_cycles_split")}
+        vi = e.get("valu_issue")
+        if vi:
+            # every VALU instruction of these kernels holds its SIMD for four cycles, so the instruction rate has a
+            # ceiling of (SIMDs x clock / 4); the clock is the one the chip held while the profiled launches ran
+            # (SQ_BUSY_CYCLES over wall time), about 1.95 GHz under this load, not the 2.4 GHz peak
+            rate = e["valu_wave_instr_per_launch"] / (avg_launch_ms * 1e-3) / 1e9
+            peak = N_SIMD * vi["clock_ghz"] / 4.0
+            r["valu_issue"] = {"bound": "valu", "achieved": round(rate, 1), "peak": round(peak, 1), "unit": "Gwave-instr/s",
+                               "frac": round(rate / peak, 4), "clock_ghz_profiled": vi["clock_ghz"],
+                               "busy_frac_profiled": vi["busy_frac"], "waves_per_simd_profiled": vi["waves_per_simd"]}
     return r
 
 

@@ -47,6 +47,24 @@ def pmc(workload, group):
     return agg
 
 
+def pmc_dispatches(workload, group):
+    """[{kernel, counters..., dur_ns}] per dispatch of one counter pass (set-up kernels dropped)."""
+    path = find(f"{workload}_{group}", "counter_collection.csv")
+    d = collections.OrderedDict()
+    for r in csv.DictReader(open(path)):
+        k = short(r["Kernel_Name"])
+        if any(s in k for s in SETUP_KERNELS):
+            continue
+        e = d.setdefault(r["Dispatch_Id"], {"kernel": k, "dur_ns": int(r["End_Timestamp"]) - int(r["Start_Timestamp"])})
+        e[r["Counter_Name"]] = float(r["Counter_Value"])
+    return list(d.values())
+
+
+N_SIMD = 256 * 4          # CUs x SIMDs
+N_SE = 32                 # shader engines (8 XCDs x 4): SQ_BUSY_CYCLES is summed over them
+N_XCD = 8                 # GRBM_GUI_ACTIVE is summed over the XCDs
+
+
 def kernel_stats(workload):
     path = find(f"{workload}_kt", "kernel_stats.csv")
     shutil.copy(path, os.path.join(P, f"{rnd}_{workload}_kernel_stats.csv"))
@@ -120,6 +138,32 @@ for wl, reps in WORKLOADS.items():
         wi = sum(sum(v[k]["SQ_WAIT_INST_ANY"]) for k in passes)
         entry["wave_cycles_split"] = {"issuing": round(1 - (wa + wi) / wc, 4), "issue_stall": round(wi / wc, 4),
                                       "waitcnt_or_barrier": round(wa / wc, 4)}
+        # VALU occupation of the SIMDs.  SQ_ACTIVE_INST_VALU counts quad-cycles (4 shader cycles; it equals
+        # SQ_INSTS_VALU here, i.e. every VALU instruction of these kernels holds its SIMD for one quad-cycle),
+        # SQ_BUSY_CYCLES counts shader cycles per shader engine, so busy/32 is the kernel's length in cycles and
+        # that over the dispatch's wall time is the clock the chip held (GRBM_GUI_ACTIVE / 8 cross-checks it).
+        disp = [x for x in pmc_dispatches(wl, "valu") if "ntt_pass_kernel" in x["kernel"]]
+        cyc = sum(x["SQ_BUSY_CYCLES"] for x in disp) / N_SE
+        entry["valu_issue"] = {
+            "busy_frac": round(4 * sum(x["SQ_ACTIVE_INST_VALU"] for x in disp) / (N_SIMD * cyc), 4),
+            "waves_per_simd": round(4 * sum(x["SQ_WAVE_CYCLES"] for x in disp) / (N_SIMD * cyc), 3),
+            "clock_ghz": round(cyc / sum(x["dur_ns"] for x in disp), 3),
+            "cycles_per_launch": round(cyc / len(disp)),
+            "per_kernel": {}}
+        for k in passes:
+            dk = [x for x in disp if x["kernel"] == k]
+            ck = sum(x["SQ_BUSY_CYCLES"] for x in dk) / N_SE
+            entry["valu_issue"]["per_kernel"][k] = {
+                "busy_frac": round(4 * sum(x["SQ_ACTIVE_INST_VALU"] for x in dk) / (N_SIMD * ck), 4),
+                "waves_per_simd": round(4 * sum(x["SQ_WAVE_CYCLES"] for x in dk) / (N_SIMD * ck), 3),
+                "valu_instr_per_wave": round(sum(x["SQ_INSTS_VALU"] for x in dk) / len(dk) / ((1 << int(wl[3:])) / 1024)),
+                "cycles": round(ck / len(dk))}
+        try:
+            g = [x for x in pmc_dispatches(wl, "grbm") if "ntt_pass_kernel" in x["kernel"]]
+            shutil.copy(find(f"{wl}_grbm", "counter_collection.csv"), os.path.join(P, f"{rnd}_{wl}_pmc_grbm.csv"))
+            entry["valu_issue"]["clock_ghz_grbm"] = round(sum(x["GRBM_GUI_ACTIVE"] for x in g) / N_XCD / sum(x["dur_ns"] for x in g), 3)
+        except FileNotFoundError:
+            pass
         n = 1 << int(wl[3:])
         w("  mean over the %d pass launches: HBM-side traffic %.1f MB per launch (algorithmic 32 B x 2^%s = %.1f MB), "
           "%.0f 64-bit-class of %.0f VALU wave-instructions" % (n_l, tr / 1e6, wl[3:], 32 * n / 1e6,
@@ -127,6 +171,14 @@ for wl, reps in WORKLOADS.items():
         w("  a resident wave's cycles: %.0f %% issuing, %.0f %% ready but held back by a busy pipe (SQ_WAIT_INST_ANY), "
           "%.0f %% parked on s_waitcnt or a barrier (SQ_WAIT_ANY)" % tuple(100 * entry["wave_cycles_split"][k] for k in
                                                                             ("issuing", "issue_stall", "waitcnt_or_barrier")))
+        vi_ = entry["valu_issue"]
+        w("  VALU pipes busy %.0f %% of the kernels' cycles (SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x SQ_BUSY_CYCLES / 32)), "
+          "%.2f waves resident per SIMD on average, clock held %.2f GHz (SQ_BUSY_CYCLES / 32 / wall%s)" %
+          (100 * vi_["busy_frac"], vi_["waves_per_simd"], vi_["clock_ghz"],
+           "; GRBM_GUI_ACTIVE / 8 / wall = %.2f" % vi_["clock_ghz_grbm"] if "clock_ghz_grbm" in vi_ else ""))
+        for k, e in vi_["per_kernel"].items():
+            w("    %-44s busy %.0f %%  %.2f waves/SIMD  %d VALU instructions per wave  %d cycles" %
+              (k[:44], 100 * e["busy_frac"], e["waves_per_simd"], e["valu_instr_per_wave"], e["cycles"]))
     else:
         entry["traffic_bytes_per_call"] = (tot_read + tot_write) / reps
         entry["valu_wave_instr_per_call"] = tot_valu / reps

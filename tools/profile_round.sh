@@ -1,7 +1,8 @@
 #!/bin/bash
 # Collects what profiles/<round>_* is made from: kernel stats of the bench command, the PMC passes of
 # the 2^22 and 2^24 transforms, of the 2^24 Merkle commitment and of the 2^24 FRI commit (each counter
-# group in a run of its own), and the compute-only hash ceiling of tools/hash_bench.hip.
+# group in a run of its own; for the transforms also GRBM_GUI_ACTIVE, the clock cross-check), and the
+# compute-only hash ceiling of tools/hash_bench.hip.
 # usage (on the GPU box, from the repository root): bash tools/profile_round.sh <out_dir>
 set -e
 R=$PWD
@@ -16,6 +17,9 @@ for W in ntt22 ntt24 merkle24 fri24; do
     timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE -d $OUT/${W}_write -o write --output-format csv -- python3 $R/tools/prof_driver.py $W $REPS > $OUT/${W}_write.log 2>&1
     timeout -s KILL 120 rocprofv3 --pmc $VALU -d $OUT/${W}_valu -o valu --output-format csv -- python3 $R/tools/prof_driver.py $W $REPS > $OUT/${W}_valu.log 2>&1
     timeout -k 10 120 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${W}_kt -o kt -- python3 $R/tools/prof_driver.py $W $REPS > $OUT/${W}_kt.log 2>&1
+    if [ $W = ntt22 ] || [ $W = ntt24 ]; then
+        timeout -s KILL 120 rocprofv3 --pmc GRBM_GUI_ACTIVE -d $OUT/${W}_grbm -o grbm --output-format csv -- python3 $R/tools/prof_driver.py $W $REPS > $OUT/${W}_grbm.log 2>&1
+    fi
 done
 if [ -x $R/tools/_build/hash_bench ]; then timeout -k 10 60 $R/tools/_build/hash_bench > $OUT/hash_bench.txt 2>&1; fi
 python3 - "$OUT" <<'PY'
