@@ -74,8 +74,14 @@ def ntt_roofline(pmc, source, key, n, avg_launch_ms, kernel):
             # (SQ_BUSY_CYCLES over wall time), about 1.95 GHz under this load, not the 2.4 GHz peak
             rate = e["valu_wave_instr_per_launch"] / (avg_launch_ms * 1e-3) / 1e9
             peak = N_SIMD * vi["clock_ghz"] / 4.0
+            # lower estimate: only the 64-bit-class instructions (multiply-adds, 64-bit shifts) at their measured
+            # 4.2 cycles and the rest at the 2.4 cycles a two-source 32-bit instruction costs when several waves share
+            # the SIMD (tools/ubench*.hip); the counter-based figure above prices every instruction at 4
+            cyc = (4.2 * e["int64_wave_instr_per_launch"] + 2.4 * (e["valu_wave_instr_per_launch"] - e["int64_wave_instr_per_launch"])) / N_SIMD
             r["valu_issue"] = {"bound": "valu", "achieved": round(rate, 1), "peak": round(peak, 1), "unit": "Gwave-instr/s",
-                               "frac": round(rate / peak, 4), "clock_ghz_profiled": vi["clock_ghz"],
+                               "frac": round(rate / peak, 4),
+                               "frac_weighted_issue_cost": round(cyc / (avg_launch_ms * 1e-3 * vi["clock_ghz"] * 1e9), 4),
+                               "clock_ghz_profiled": vi["clock_ghz"],
                                "busy_frac_profiled": vi["busy_frac"], "waves_per_simd_profiled": vi["waves_per_simd"]}
     return r
 
