@@ -321,6 +321,35 @@ def test_proof_bytes_equal_restatement(hm, log_rows):
         job.free()
 
 
+VARIANTS = ["rows=2,e=4,c=2,in=5", "rows=3,e=4,c=2,in=5", "rows=100,e=8,c=3,in=7", "rows=513,e=8,c=4,in=11",
+            "rows=1000,e=4,c=4,in=99", "rows=1000,e=4,c=5,in=99", "rows=3000,e=16,c=2,in=3", "rows=65537,e=4,c=2,in=8"]
+
+
+@pytest.mark.parametrize("key", VARIANTS)
+def test_proof_bytes_other_lengths_and_parameters(hm, key):
+    """Trace lengths that are not powers of two (down to the minimum of two rows), other expansion factors,
+    numbers of colinearity tests and inputs, against the restatement's committed vectors.  One case
+    (1000 rows, 5 colinearity tests) sits where stark.rs:44-58, which sizes the domains for constraints of
+    degree 2, leaves the FRI domain too small for the degree-3 Rescue-Prime constraints: the restatement's
+    verifier rejects the restatement's own proof there, and the device prover and the mirror's verifier must do
+    the same with the same bytes."""
+    g = _golden(key)
+    rows = g["rows"]
+    job = _Chain(hm, int(g["input"]), rows, g["expansion"], g["ncol"], g["security"])
+    try:
+        assert job.output == int(g["output"]) and job.random_bytes == g["random_bytes"]
+        assert hm.lib.sh_chain_fri_domain_length(job.h) == g["fri_domain"]
+        random = hashlib.shake_256(g["seed"].encode()).digest(g["random_bytes"])
+        proof, used = job.prove(random)
+        assert used == len(random)
+        assert len(proof) == g["proof_len"]
+        assert hashlib.sha256(proof).hexdigest() == g["proof_sha256"]
+        assert job.verify(job.output, proof) == (1 if g["verifies"] else 0)
+        assert job.verify((job.output + 1) % P, proof) == 0
+    finally:
+        job.free()
+
+
 def test_2_20_rows_both_verifiers(hm):
     """The scaled workload: a 2^20-row Rescue-Prime chain, FRI domain 2^24.  The mirror's verifier and the
     Python restatement's verifier (which evaluates the constant columns through the Lagrange basis

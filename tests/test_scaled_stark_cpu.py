@@ -100,6 +100,26 @@ def test_committed_vectors(rp, log_rows):
     assert len(proof) == g["proof_len"] and hashlib.sha256(proof).hexdigest() == g["proof_sha256"]
 
 
+@pytest.mark.parametrize("key", ["rows=2,e=4,c=2,in=5", "rows=3,e=4,c=2,in=5", "rows=100,e=8,c=3,in=7",
+                                 "rows=513,e=8,c=4,in=11", "rows=1000,e=4,c=5,in=99"])
+def test_committed_vectors_other_lengths_and_parameters(rp, key):
+    """The vectors for trace lengths that are not powers of two and for other parameters are reproduced, the
+    one the verifier must reject included (FRI domain too small for the constraints' degree, stark.rs:44-58)."""
+    with open(os.path.join(ROOT, "tests", "golden", "scaled_stark.json")) as f:
+        g = json.load(f)[key]
+    rows = g["rows"]
+    st = ss.ScaledStark(g["expansion"], g["ncol"], g["security"], rp.m, rows)
+    trace = ss.rescue_chain_trace(rp, int(g["input"]), rows)
+    assert trace[-1][0] == int(g["output"])
+    air, cols = ss.rescue_column_air(rp), ss.rescue_constant_columns(rp, rows)
+    boundary = ss.rescue_chain_boundary(rp, rows, trace[-1][0])
+    assert st.fri_domain_length == g["fri_domain"] and st.max_degree(air) == g["max_degree"]
+    proof = st.prove(trace, air, cols, boundary, ss.stream_rng(g["seed"].encode(), g["random_bytes"]))
+    assert len(proof) == g["proof_len"] and hashlib.sha256(proof).hexdigest() == g["proof_sha256"]
+    assert st.verify(proof, air, cols, boundary) == g["verifies"]
+    assert g["verifies"] == (g["max_degree"] < g["fri_domain"] // g["expansion"])
+
+
 def test_verifier_rejects(rp):
     rows = 64
     st = ss.ScaledStark(4, 2, 2, rp.m, rows)
