@@ -147,13 +147,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # Rehearsal of the N > 1 code path where only one GPU exists: every rank uses GPU 0 and gloo carries the
+    # collectives (STARK_BENCH_SHARE_GPU=1).  Its numbers mean nothing; it is there to run the code.
+    share_gpu = world > 1 and os.environ.get("STARK_BENCH_SHARE_GPU") == "1"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if share_gpu:
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    dev = torch.device("cuda", local_rank if world > 1 and not share_gpu else 0)
 
     from stark_amd import Context, GENERATOR
     from stark_amd.synth import field_vector
@@ -197,7 +204,7 @@ def main():
     dt = time.perf_counter() - t0
     kernel_ms_total = ev_start.elapsed_time(ev_stop)
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], device="cpu" if share_gpu else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     # the transform pair must give the input back, bit for bit
@@ -219,7 +226,7 @@ def main():
             "dtype": "u128 (mod 407*2^119+1)", "data": "synthetic",
             "config": {"workload": "single 2^22-point forward+inverse NTT per GPU, data resident in HBM",
                        "log_n": LOG_N, "elements_per_step": 2 * n, "parallelism": f"independent x{world}",
-                       "ramp_ms": args.ramp_ms},
+                       "ramp_ms": args.ramp_ms, **({"rehearsal": "all ranks on one GPU, gloo"} if share_gpu else {})},
             "roofline": ntt_roofline(pmc, pmc_source, "ntt22", n, avg_launch_ms,
                                      "ntt_pass_kernel (3 launches per transform)"),
         }
