@@ -317,7 +317,9 @@ constexpr uint32_t PLANE_MAX_LOG = 26;
 static std::vector<uint32_t> plan_radices(uint32_t log_n)
 {
     std::vector<uint32_t> r;
-    if (log_n < (uint32_t)PASS_MIN_LOG) return r;
+    if (log_n < (uint32_t)SHORT_MIN_LOG) return r;
+    if (log_n <= 8) return {log_n};                           // one pass; a tile spans 4096 / n transforms
+    if (log_n == 9) return {4, 5};                            // radix 16 (no exchange), then 32
     uint32_t P = (log_n + 7) / 8;
     uint32_t base = log_n / P, rem = log_n % P;
     for (uint32_t q = 0; q < P; q++) r.push_back(base + (q < rem ? 1 : 0));
@@ -349,24 +351,34 @@ static int32_t get_ntt_tables(stark_ctx* ctx, uint32_t log_n, bool inverse, cons
     fe n_inv = F.inverse(fe{(u64)1 << log_n, 0});             // ntt.rs:36
     t.scale_m = F.to_mont(n_inv);
     int32_t rc = STARK_OK;
-    if (log_n < (uint32_t)PASS_MIN_LOG) {
+    if (log_n <= 8) {                                         // the single-workgroup kernel: n < 32, coset and padded transforms
         size_t half = log_n ? ((size_t)1 << (log_n - 1)) : 1;
         rc = upload(ctx, powers_m(F, omega, half), &t.small);
-    } else {
+    }
+    if (rc == STARK_OK && log_n >= (uint32_t)SHORT_MIN_LOG) {
         t.radices = plan_radices(log_n);
         t.h = t.radices.back();
-        fe w16 = F.pow(omega, (u128)1 << (log_n - 4));
-        fe w256 = F.pow(omega, (u128)1 << (log_n - 8));
+        fe w16 = F.primitive_nth_root(4), w256 = F.primitive_nth_root(8);   // omega^(n/16), omega^(n/256) where n allows
+        if (inverse) {
+            w16 = F.inverse(w16);
+            w256 = F.inverse(w256);
+        }
         fe w_hi = F.pow(omega, (u128)1 << t.h);
         // the kernels carry the powers of the 16th root as literals (tw16_tables.hpp); they must be the
         // powers of THIS root
-        if (!tw16_literals_match(F, w16, inverse))
+        if (!tw16_literals_match(F, w16, inverse)) {
+            free_ntt_tables(t);
             return fail(STARK_EARG, "the compiled-in 16th-root table does not match primitive_nth_root");
-        rc = upload(ctx, powers_5(F, w256, 256), &t.tw256);
+        }
+        // a one-pass inverse has no outgoing twiddle to carry n^-1 (ntt.rs:36-39): it rides on the exchange
+        // twiddles instead, which every element meets exactly once
+        const bool one_pass = t.radices.size() == 1;
+        rc = upload(ctx, powers_5(F, w256, 256, (inverse && one_pass) ? n_inv : fe{1, 0}), &t.tw256);
         if (rc == STARK_OK) rc = upload(ctx, powers_5(F, w_hi, (size_t)1 << (log_n - t.h)), &t.hi);
         // ntt.rs:36-39: the inverse's n^-1 rides on the lo table, which enters exactly one product per
         // element (the outgoing twiddle of the pass before the last); the last pass multiplies nothing
-        if (rc == STARK_OK) rc = upload(ctx, powers_5(F, omega, (size_t)1 << t.h, inverse ? n_inv : fe{1, 0}), &t.lo);
+        if (rc == STARK_OK)
+            rc = upload(ctx, powers_5(F, omega, (size_t)1 << t.h, (inverse && !one_pass) ? n_inv : fe{1, 0}), &t.lo);
     }
     if (rc != STARK_OK) {
         free_ntt_tables(t);                                   // nothing half-built stays behind
@@ -434,9 +446,12 @@ static int32_t run_ntt(stark_ctx* ctx, const fe* src, size_t src_stride, size_t 
     const NttTables* t;
     ST_TRY(get_ntt_tables(ctx, log_n, inverse, &t));
     const size_t n = (size_t)1 << log_n;
+    // the tiled passes take everything from 512 points up, and plain transforms (no coset shift, no zero
+    // padding) from 32 points; the rest runs in one workgroup
+    const bool tiled = log_n >= 9 || (log_n >= (uint32_t)SHORT_MIN_LOG && !twist_x && n_src == n);
     PowRef twist;
-    if (twist_x) ST_TRY(get_pow_tables(ctx, *twist_x, n_src, log_n >= (uint32_t)PASS_MIN_LOG, &twist));
-    if (log_n < (uint32_t)PASS_MIN_LOG) {
+    if (twist_x) ST_TRY(get_pow_tables(ctx, *twist_x, n_src, tiled, &twist));
+    if (!tiled) {
         SmallArgs a{};
         a.tw = t->small;
         a.twist_hi = twist ? (const fe*)twist->hi : nullptr;
@@ -495,6 +510,7 @@ static int32_t run_ntt(stark_ctx* ctx, const fe* src, size_t src_stride, size_t 
                 a.src = ctx->scratch;
                 a.src_batch_stride = n;
             }
+            if (P == 1) mode = PASS_LAST;                     // rows in, natural order out: the one pass is a last pass
             if (q == P - 1) {
                 a.dst = dst + c0 * dst_stride;
                 a.dst_batch_stride = dst_stride;

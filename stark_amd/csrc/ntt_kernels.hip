@@ -226,7 +226,7 @@ struct Geo {
     static constexpr int PITCH = (MODE == PASS_LAST) ? (C + 1) : C;
     static constexpr int TWSHIFT = 8 - (RA + 4);
     static constexpr int KA_HALF = M1 / 2;      // the exchange runs in two phases of M1/2 values of ka
-    static constexpr int LDS_ELEMS = (R / 2) * PITCH;
+    static constexpr int LDS_ELEMS = RA == 0 ? 1 : (R / 2) * PITCH;   // a radix-16 pass has no exchange
 };
 
 // canonical loads -> lazy limbs, plus the coset twist of a first pass.  The
@@ -489,17 +489,21 @@ __global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(3,
 {
     using G = Geo<RA, MODE>;
     __shared__ fe5 lds[G::LDS_ELEMS];
-    __shared__ tw5 s_tw256[256];
+    __shared__ tw5 s_tw256[RA == 0 ? 1 : 256];
     const int t = threadIdx.x;
-    s_tw256[t] = a.tw256[t];
+    if constexpr (RA > 0) s_tw256[t] = a.tw256[t];
 
     const uint64_t tile = blockIdx.x;
     fe raw[16];
     fe5 v[16];
     load_tile<RA, MODE, SMALL>(raw, a, tile, t);
     unpack_tile<RA, MODE, TWIST, SMALL>(v, raw, a, tile, t);
-    lds_barrier();          // s_tw256 staged
-    round1_exchange<RA, MODE, INV>(v, lds, s_tw256, t);
+    // RA = 0 (radix 16, first pass only): load_tile has already put the 16 points of column t into this
+    // thread's registers, which is the layout round 2 starts from: no first round, no exchange
+    if constexpr (RA > 0) {
+        lds_barrier();          // s_tw256 staged
+        round1_exchange<RA, MODE, INV>(v, lds, s_tw256, t);
+    }
     round2_store<RA, MODE, NEXT_LAST, SMALL, INV>(v, a, tile, t);
 }
 
@@ -529,33 +533,55 @@ template <int RA, bool SMALL>
 static hipError_t launch_ra(const PassArgs& a, PassMode mode, bool twist, hipStream_t s)
 {
     const int nl = a.next_is_last ? (a.plane ? 2 : 1) : 0;
+    // shapes that no plan uses are not built: a radix-16 pass is only ever the first of two, and a pass of
+    // 128 or 256 points over a shared tile is only ever the single pass of a transform of that length
+    if constexpr (RA == 0) {
+        if (mode != PASS_FIRST || nl == 0) return hipErrorInvalidValue;
+    }
+    if constexpr (SMALL && RA >= 3) {
+        if (mode != PASS_LAST) return hipErrorInvalidValue;
+        return launch_one<RA, PASS_LAST, false, 0, SMALL>(a, s);
+    } else {
     switch (mode) {
     case PASS_FIRST:
+        if constexpr (RA == 0) {
+            if (twist) return nl == 2 ? launch_one<RA, PASS_FIRST, true, 2, SMALL>(a, s)
+                                      : launch_one<RA, PASS_FIRST, true, 1, SMALL>(a, s);
+            return nl == 2 ? launch_one<RA, PASS_FIRST, false, 2, SMALL>(a, s)
+                           : launch_one<RA, PASS_FIRST, false, 1, SMALL>(a, s);
+        } else {
         if (twist) return nl == 2 ? launch_one<RA, PASS_FIRST, true, 2, SMALL>(a, s)
                    : nl == 1      ? launch_one<RA, PASS_FIRST, true, 1, SMALL>(a, s)
                                   : launch_one<RA, PASS_FIRST, true, 0, SMALL>(a, s);
         return nl == 2 ? launch_one<RA, PASS_FIRST, false, 2, SMALL>(a, s)
                : nl == 1 ? launch_one<RA, PASS_FIRST, false, 1, SMALL>(a, s)
                          : launch_one<RA, PASS_FIRST, false, 0, SMALL>(a, s);
+        }
     case PASS_MIDDLE:
-        if constexpr (SMALL) return hipErrorInvalidValue;      // short transforms take two passes: no middle one
+        if constexpr (SMALL) return hipErrorInvalidValue;      // short transforms take at most two passes: no middle one
         else return nl == 2 ? launch_one<RA, PASS_MIDDLE, false, 2, false>(a, s)
                     : nl == 1 ? launch_one<RA, PASS_MIDDLE, false, 1, false>(a, s)
                               : launch_one<RA, PASS_MIDDLE, false, 0, false>(a, s);
-    case PASS_LAST: return launch_one<RA, PASS_LAST, false, 0, SMALL>(a, s);
+    case PASS_LAST:
+        if constexpr (RA == 0) return hipErrorInvalidValue;
+        else return launch_one<RA, PASS_LAST, false, 0, SMALL>(a, s);
     }
     return hipErrorInvalidValue;
+    }
 }
 
 hipError_t launch_ntt_pass(const PassArgs& a_in, PassMode mode, bool twist, uint32_t n_batch, hipStream_t s)
 {
-    if (a_in.log_n < (uint32_t)PASS_MIN_LOG || a_in.log_n > 30) return hipErrorInvalidValue;
+    if (a_in.log_n < (uint32_t)SHORT_MIN_LOG || a_in.log_n > 30 || a_in.r > a_in.log_n) return hipErrorInvalidValue;
     PassArgs a = a_in;
     a.n_batch = n_batch;
     if (a.log_n < 12) {                                        // several transforms share a 4096-element tile
         switch (a.r) {
+        case 4: return launch_ra<0, true>(a, mode, twist, s);
         case 5: return launch_ra<1, true>(a, mode, twist, s);
         case 6: return launch_ra<2, true>(a, mode, twist, s);
+        case 7: return launch_ra<3, true>(a, mode, twist, s);
+        case 8: return launch_ra<4, true>(a, mode, twist, s);
         }
         return hipErrorInvalidValue;
     }
@@ -569,7 +595,8 @@ hipError_t launch_ntt_pass(const PassArgs& a_in, PassMode mode, bool twist, uint
 }
 
 // ---------------------------------------------------------------------------
-// n < 1024: the whole transform lives in one workgroup's LDS.
+// n < 32, and coset or zero-padded transforms of fewer than 512 points: the whole transform lives in
+// one workgroup's LDS.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(TILE_THREADS) void ntt_small_kernel(SmallArgs a)
 {

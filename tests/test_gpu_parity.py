@@ -77,7 +77,10 @@ def test_ntt_2_24_full_size(ctx):
 
 def test_ntt_batch(ctx):
     # 2^10 and 2^11: several transforms share a 4096-element tile, the last tile reaching past the batch
-    for log_n, cols in ((5, 7), (13, 5), (16, 3), (10, 1), (10, 7), (10, 8), (11, 3), (11, 130)):
+    # 2^5 .. 2^8: one pass, 128 .. 16 transforms to a tile; 2^9: a radix-16 pass without exchange, then radix 32
+    for log_n, cols in ((5, 7), (13, 5), (16, 3), (10, 1), (10, 7), (10, 8), (11, 3), (11, 130),
+                        (5, 1), (5, 128), (5, 129), (6, 65), (7, 1), (7, 33), (8, 16), (8, 17), (8, 1000),
+                        (9, 1), (9, 8), (9, 9), (9, 300), (4, 5), (3, 300)):
         n = 1 << log_n
         x = oc.splitmix(n * cols, 77 + log_n).reshape(cols, n, 2)
         out = ctx.ntt_batch(x)
@@ -85,6 +88,25 @@ def test_ntt_batch(ctx):
             assert np.array_equal(out[c], oc.ntt(x[c]))
         back = ctx.ntt_batch(out, inverse=True)
         assert np.array_equal(back, x)
+
+
+@pytest.mark.parametrize("log_n,cols", [(5, 40), (8, 19), (9, 11), (10, 5)])
+def test_ntt_batch_strided_columns_in_place(ctx, log_n, cols):
+    """Short transforms sharing a tile, columns further apart than their length, transformed in place on the
+    device: the gaps between the columns must come back untouched."""
+    import torch
+    n, stride = 1 << log_n, (1 << log_n) + 3
+    x = oc.splitmix(stride * cols, 500 + log_n).reshape(cols, stride, 2)
+    d = torch.from_numpy(x.view(np.int64).copy()).cuda()
+    ctx.ntt_dev(d, n, False, n_cols=cols, col_stride=stride)
+    torch.cuda.synchronize()
+    got = d.cpu().numpy().view(np.uint64).reshape(cols, stride, 2)
+    for c in range(cols):
+        assert np.array_equal(got[c, :n], oc.ntt(np.ascontiguousarray(x[c, :n])))
+        assert np.array_equal(got[c, n:], x[c, n:])
+    ctx.ntt_dev(d, n, True, n_cols=cols, col_stride=stride)
+    torch.cuda.synchronize()
+    assert np.array_equal(d.cpu().numpy().view(np.uint64).reshape(cols, stride, 2), x)
 
 
 def test_ntt_errors(ctx):

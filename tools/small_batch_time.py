@@ -15,7 +15,7 @@ ctx = Context(0)
 ctx.set_stream(torch.cuda.current_stream().cuda_stream)
 total = 1 << 24
 d = torch.from_numpy(field_vector(total, 5).view(np.int64)).cuda()
-for log_n in (8, 10, 11, 12, 13, 14, 16, 24):
+for log_n in (4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 16, 24):
     n = 1 << log_n
     cols = total // n
     for _ in range(2):
