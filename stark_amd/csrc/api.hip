@@ -1198,28 +1198,33 @@ extern "C" int32_t stark_mpoly_eval_dev(stark_ctx* ctx, size_t n_vars, const uin
         a.cols[v] = (const fe*)cols_dev[v];
         a.rot[v] = rotations ? rotations[v] % n : 0;
     }
-    // term table: Montgomery-form coefficients, then 16 exponent bytes per term
-    const size_t coef_bytes = (n_terms ? n_terms : 1) * sizeof(fe);
+    // term table: five-limb forms of the coefficients, then 16 exponent bytes per term
+    const size_t coef_bytes = (n_terms ? n_terms : 1) * sizeof(tw5);
     std::vector<uint8_t> table(coef_bytes + (n_terms ? n_terms : 1) * MPOLY_MAX_VARS, 0);
     for (size_t k = 0; k < n_terms; k++) {
         fe c{coeffs[2 * k], coeffs[2 * k + 1]};
         if (!is_canonical(c)) return fail(STARK_EARG, "scalar not reduced modulo p");
-        fe cm = ctx->F.to_mont(c);
-        memcpy(table.data() + k * sizeof(fe), &cm, sizeof(fe));
+        tw5 cm = to_tw5(ctx->F, c);
+        memcpy(table.data() + k * sizeof(tw5), &cm, sizeof(tw5));
         for (size_t v = 0; v < n_vars; v++) table[coef_bytes + k * MPOLY_MAX_VARS + v] = exps[k * n_vars + v];
     }
     DevBuf tb(ctx);
     ST_TRY(tb.alloc(table.size()));
     HIP_TRY(hipMemcpyAsync(tb.p, table.data(), table.size(), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));              // `table` is pageable host memory about to go away
-    a.coef_m = (const fe*)tb.p;
+    a.coef5 = (const tw5*)tb.p;
     a.exps = (const uint8_t*)tb.p + coef_bytes;
     a.mul = (const fe*)mul_dev;
     a.out = (fe*)out_dev;
     a.n = n;
     a.n_vars = (uint32_t)n_vars;
     a.n_terms = (uint32_t)n_terms;
-    a.r2 = ctx->F.r2;
+    a.scaled_one = to_tw5(ctx->F, fe{1, 0});
+    {
+        fe r156{1, 0};
+        for (int b = 0; b < 156; b++) r156 = fe_add(r156, r156);
+        a.scale_in = to_tw5(ctx->F, r156);
+    }
     HIP_TRY(launch_mpoly_eval(a, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));              // the table block returns to the cache on return
     return STARK_OK;

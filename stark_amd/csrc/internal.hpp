@@ -154,13 +154,14 @@ constexpr uint32_t MPOLY_MAX_VARS = 16;
 struct MPolyArgs {
     const fe* cols[MPOLY_MAX_VARS];      // variable v at point i: cols[v][(i + rot[v]) mod n]
     uint64_t rot[MPOLY_MAX_VARS];
-    const fe* coef_m;                    // n_terms coefficients, Montgomery form (device memory)
+    const tw5* coef5;                    // n_terms coefficients as five-limb forms c * 2^156 (device memory)
     const uint8_t* exps;                 // n_terms x MPOLY_MAX_VARS exponents (device memory)
     const fe* mul;                       // optional pointwise factor
     fe* out;
     uint64_t n;
     uint32_t n_vars, n_terms;
-    fe r2;
+    tw5 scale_in;                        // five-limb form of 2^156: brings a loaded value into the scaled domain
+    tw5 scaled_one;                      // five-limb form of 1: a product by it only renormalises the limbs
 };
 hipError_t launch_mpoly_eval(const MPolyArgs& a, hipStream_t s);
 // *result_dev (zeroed by the caller) = 1 + largest index of a nonzero coefficient, 0 if none

@@ -8,6 +8,7 @@
 // product.
 #include <hip/hip_runtime.h>
 
+#include "field5.hpp"
 #include "internal.hpp"
 
 namespace starkk {
@@ -127,39 +128,53 @@ hipError_t launch_lincomb(const LincombArgs& a, hipStream_t s)
 // given the value is multiplied by mul[i] on the way out (the division by a
 // zeroifier whose inverse values are at hand, stark.rs:336-341).
 constexpr int MPOLY_THREADS = 128;
+constexpr int MPOLY_LAZY_TERMS = 16;       // lazy sums of this many products keep their limbs below 2^31
 __global__ __launch_bounds__(MPOLY_THREADS) void mpoly_eval_kernel(MPolyArgs a)
 {
-    __shared__ fe pt[MPOLY_MAX_VARS][MPOLY_THREADS];
+    // The arithmetic is the transform passes' lazy five-limb core (219 cycles a product against 391 on two
+    // 64-bit words).  Values live scaled by 2^156, the factor a five-limb product divides by, so products of
+    // scaled values are scaled values; the last product, by mul[i] or by 1 unscaled, takes the factor out.
+    __shared__ fe5 pt[MPOLY_MAX_VARS][MPOLY_THREADS];
     const uint32_t t = threadIdx.x;
     const uint64_t i = (uint64_t)blockIdx.x * MPOLY_THREADS + t;
     if (i >= a.n) return;
     for (uint32_t v = 0; v < a.n_vars; v++) {
         uint64_t idx = i + a.rot[v];
         if (idx >= a.n) idx -= a.n;
-        pt[v][t] = mont_mul(a.cols[v][idx], a.r2);
+        pt[v][t] = mont_mul5_s(unpack5(a.cols[v][idx]), a.scale_in);
     }
-    fe acc = fe_zero();
+    fe5 acc{{0, 0, 0, 0, 0}};
+    uint32_t pending = 0;
     for (uint32_t k = 0; k < a.n_terms; k++) {
-        fe prod = a.coef_m[k];
+        bool started = false;
+        fe5 prod{};
         const uint8_t* __restrict__ ex = a.exps + (size_t)k * MPOLY_MAX_VARS;
         for (uint32_t v = 0; v < a.n_vars; v++) {
             uint32_t e = ex[v];
             if (e == 0) continue;
-            fe b = pt[v][t];
+            const fe5 b = pt[v][t];
             // left-to-right over the bits of e: e is small (the AIR's degree)
-            fe p = b;
+            fe5 p = b;
             int top = 31 - __builtin_clz(e);
             for (int bit = top - 1; bit >= 0; bit--) {
-                p = mont_mul(p, p);
-                if ((e >> bit) & 1) p = mont_mul(p, b);
+                p = mont_mul5_v(p, p);
+                if ((e >> bit) & 1) p = mont_mul5_v(p, b);
             }
-            prod = mont_mul(prod, p);
+            prod = started ? mont_mul5_v(prod, p) : p;
+            started = true;
         }
-        acc = fe_add(acc, prod);
+        // the coefficient last: it is the same for every thread and is read through the scalar path
+        const tw5 c = a.coef5[k];
+        prod = started ? mont_mul5_s(prod, c) : fe5{{c.l[0], c.l[1], c.l[2], c.l[3], c.l[4]}};
+        acc = add5(acc, prod);
+        if (++pending == MPOLY_LAZY_TERMS) {
+            acc = mont_mul5_s(acc, a.scaled_one);
+            pending = 1;
+        }
     }
-    fe o = mont_mul(acc, fe{1, 0});                          // out of Montgomery form
-    if (a.mul) o = mont_mul(mont_mul(o, a.mul[i]), a.r2);
-    a.out[i] = o;
+    fe5 w{{1, 0, 0, 0, 0}};
+    if (a.mul) w = unpack5(a.mul[i]);
+    a.out[i] = pack_canonical(mont_mul5_v(acc, w));
 }
 
 hipError_t launch_mpoly_eval(const MPolyArgs& a, hipStream_t s)
