@@ -104,6 +104,50 @@ template <int KIND> __global__ __launch_bounds__(256) void probe(uint32_t* out, 
 #define M(y) asm volatile("v_xor_b32_e32 %0, %1, %0" : "+v"(y) : "s"(seed));
             REP32(M)
 #undef M
+        } else if constexpr (KIND == 22) {   // xor of selected words, written to one word of the destination (SDWA)
+#define M(y) asm volatile("v_xor_b32_sdwa %0, %0, %1 dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_1" : "+v"(y) : "v"(b));
+            REP32(M)
+#undef M
+        } else if constexpr (KIND == 23) {   // SDWA xor writing the whole destination
+#define M(y) asm volatile("v_xor_b32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:BYTE_2" : "+v"(y) : "v"(b));
+            REP32(M)
+#undef M
+        } else if constexpr (KIND == 24) {   // v_mad_i64_i32 with a vector multiplier
+            uint64_t z0 = y0, z1 = y1, z2 = y2, z3 = y3, z4 = y4, z5 = y5, z6 = y6, z7 = y7;
+#define M(z) asm volatile("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(z) : "v"(b), "v"(c) : "vcc");
+#define R4 M(z0) M(z1) M(z2) M(z3) M(z4) M(z5) M(z6) M(z7)
+            R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4
+            y4 ^= (uint32_t)z4; y5 ^= (uint32_t)z5; y6 ^= (uint32_t)z6; y7 ^= (uint32_t)z7;
+#undef R4
+#undef M
+            y0 ^= (uint32_t)z0; y1 ^= (uint32_t)z1; y2 ^= (uint32_t)z2; y3 ^= (uint32_t)z3;
+        } else if constexpr (KIND == 25) {   // v_mad_i64_i32 with a scalar multiplier
+            uint64_t z0 = y0, z1 = y1, z2 = y2, z3 = y3, z4 = y4, z5 = y5, z6 = y6, z7 = y7;
+#define M(z) asm volatile("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(z) : "v"(b), "s"(seed) : "vcc");
+#define R4 M(z0) M(z1) M(z2) M(z3) M(z4) M(z5) M(z6) M(z7)
+            R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4
+            y4 ^= (uint32_t)z4; y5 ^= (uint32_t)z5; y6 ^= (uint32_t)z6; y7 ^= (uint32_t)z7;
+#undef R4
+#undef M
+            y0 ^= (uint32_t)z0; y1 ^= (uint32_t)z1; y2 ^= (uint32_t)z2; y3 ^= (uint32_t)z3;
+        } else if constexpr (KIND == 26) {   // v_ashrrev_i64
+            uint64_t z0 = y0, z1 = y1, z2 = y2, z3 = y3, z4 = y4, z5 = y5, z6 = y6, z7 = y7;
+#define M(z) asm volatile("v_ashrrev_i64 %0, 3, %0" : "+v"(z));
+#define R4 M(z0) M(z1) M(z2) M(z3) M(z4) M(z5) M(z6) M(z7)
+            R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4
+            y4 ^= (uint32_t)z4; y5 ^= (uint32_t)z5; y6 ^= (uint32_t)z6; y7 ^= (uint32_t)z7;
+#undef R4
+#undef M
+            y0 ^= (uint32_t)z0; y1 ^= (uint32_t)z1; y2 ^= (uint32_t)z2; y3 ^= (uint32_t)z3;
+        } else if constexpr (KIND == 27) {   // v_lshl_add_u64
+            uint64_t z0 = y0, z1 = y1, z2 = y2, z3 = y3, z4 = y4, z5 = y5, z6 = y6, z7 = y7, w = ((uint64_t)c << 32) | b;
+#define M(z) asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(z) : "v"(w));
+#define R4 M(z0) M(z1) M(z2) M(z3) M(z4) M(z5) M(z6) M(z7)
+            R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4 R4
+            y4 ^= (uint32_t)z4; y5 ^= (uint32_t)z5; y6 ^= (uint32_t)z6; y7 ^= (uint32_t)z7;
+#undef R4
+#undef M
+            y0 ^= (uint32_t)z0; y1 ^= (uint32_t)z1; y2 ^= (uint32_t)z2; y3 ^= (uint32_t)z3;
         } else if constexpr (KIND == 21) {   // v_mov_b32
 #define M(y) asm volatile("v_mov_b32_e32 %0, %1" : "=v"(y) : "v"(b));
             REP32(M)
@@ -178,6 +222,7 @@ __global__ __launch_bounds__(256) void clock_probe(uint64_t* out, uint32_t seed)
 
 template <int KIND> int run(const char* name, uint32_t* d)
 {
+    constexpr int PER_ITER = (KIND >= 24 && KIND <= 27) ? 256 : 32;     // instructions of the kind per loop iteration
     const int blocks = 256 * 8, threads = 256;
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
@@ -189,7 +234,7 @@ template <int KIND> int run(const char* name, uint32_t* d)
     CHECK(hipEventSynchronize(e1));
     float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
     double waves = 5.0 * blocks * threads / 64;
-    double winstr = waves * ITERS * 32;
+    double winstr = waves * ITERS * PER_ITER;
     double per_s = winstr / (ms * 1e-3);
     double cyc = 2.4e9 * 1024 / per_s;
     printf("%-28s %8.3f ms  %9.2f Gwave-instr/s  ~%5.2f cyc/wave-instr/SIMD @2.4GHz\n", name, ms, per_s / 1e9, cyc);
@@ -221,6 +266,12 @@ int main()
     run<14>("v_xor_b32_dpp quad_perm", d);
     run<15>("add_co+addc pair (per instr)", d);
     run<18>("v_pk_add_u16", d);
+    run<22>("v_xor_b32_sdwa word->word", d);
+    run<23>("v_xor_b32_sdwa dword dest", d);
+    run<24>("v_mad_i64_i32 vgpr", d);
+    run<25>("v_mad_i64_i32 sgpr", d);
+    run<26>("v_ashrrev_i64", d);
+    run<27>("v_lshl_add_u64", d);
     for (int blocks : {256, 512, 1024, 2048}) {
         run_long<0>("straight-line 16 KB xor e32", d, blocks);
         run_long<1>("straight-line 32 KB xor e64", d, blocks);
