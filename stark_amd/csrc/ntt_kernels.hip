@@ -529,45 +529,44 @@ static hipError_t launch_one(const PassArgs& a, hipStream_t s)
     return launch_dir<RA, MODE, TWIST, NEXT_LAST, SMALL, false>(a, s);
 }
 
+// The first-pass instantiations of one radix: with or without the coset twist, and by where the twiddle
+// of the next pass comes from (nl: 0 = hi table, the next pass is not the last; 1 = hi * lo; 2 = plane).
+template <int RA, bool SMALL>
+static hipError_t launch_first(const PassArgs& a, bool twist, int nl, hipStream_t s)
+{
+    if (twist) {
+        if (nl == 2) return launch_one<RA, PASS_FIRST, true, 2, SMALL>(a, s);
+        if (nl == 1) return launch_one<RA, PASS_FIRST, true, 1, SMALL>(a, s);
+        if constexpr (RA == 0) return hipErrorInvalidValue;    // a radix-16 pass is always followed by the last pass
+        else return launch_one<RA, PASS_FIRST, true, 0, SMALL>(a, s);
+    }
+    if (nl == 2) return launch_one<RA, PASS_FIRST, false, 2, SMALL>(a, s);
+    if (nl == 1) return launch_one<RA, PASS_FIRST, false, 1, SMALL>(a, s);
+    if constexpr (RA == 0) return hipErrorInvalidValue;
+    else return launch_one<RA, PASS_FIRST, false, 0, SMALL>(a, s);
+}
+
+// Shapes that no plan uses are not built: a radix-16 pass (RA = 0) is only ever the first of two, a pass of
+// 128 or 256 points over a shared tile only ever the single pass of a transform of that length, and
+// transforms that share tiles take at most two passes.
 template <int RA, bool SMALL>
 static hipError_t launch_ra(const PassArgs& a, PassMode mode, bool twist, hipStream_t s)
 {
+    constexpr bool FIRST_ONLY = RA == 0;
+    constexpr bool LAST_ONLY = SMALL && RA >= 3;
     const int nl = a.next_is_last ? (a.plane ? 2 : 1) : 0;
-    // shapes that no plan uses are not built: a radix-16 pass is only ever the first of two, and a pass of
-    // 128 or 256 points over a shared tile is only ever the single pass of a transform of that length
-    if constexpr (RA == 0) {
-        if (mode != PASS_FIRST || nl == 0) return hipErrorInvalidValue;
+    if (mode == PASS_FIRST) {
+        if constexpr (LAST_ONLY) return hipErrorInvalidValue;
+        else return launch_first<RA, SMALL>(a, twist, nl, s);
     }
-    if constexpr (SMALL && RA >= 3) {
-        if (mode != PASS_LAST) return hipErrorInvalidValue;
-        return launch_one<RA, PASS_LAST, false, 0, SMALL>(a, s);
-    } else {
-    switch (mode) {
-    case PASS_FIRST:
-        if constexpr (RA == 0) {
-            if (twist) return nl == 2 ? launch_one<RA, PASS_FIRST, true, 2, SMALL>(a, s)
-                                      : launch_one<RA, PASS_FIRST, true, 1, SMALL>(a, s);
-            return nl == 2 ? launch_one<RA, PASS_FIRST, false, 2, SMALL>(a, s)
-                           : launch_one<RA, PASS_FIRST, false, 1, SMALL>(a, s);
-        } else {
-        if (twist) return nl == 2 ? launch_one<RA, PASS_FIRST, true, 2, SMALL>(a, s)
-                   : nl == 1      ? launch_one<RA, PASS_FIRST, true, 1, SMALL>(a, s)
-                                  : launch_one<RA, PASS_FIRST, true, 0, SMALL>(a, s);
-        return nl == 2 ? launch_one<RA, PASS_FIRST, false, 2, SMALL>(a, s)
-               : nl == 1 ? launch_one<RA, PASS_FIRST, false, 1, SMALL>(a, s)
-                         : launch_one<RA, PASS_FIRST, false, 0, SMALL>(a, s);
-        }
-    case PASS_MIDDLE:
-        if constexpr (SMALL) return hipErrorInvalidValue;      // short transforms take at most two passes: no middle one
+    if (mode == PASS_MIDDLE) {
+        if constexpr (SMALL || FIRST_ONLY) return hipErrorInvalidValue;
         else return nl == 2 ? launch_one<RA, PASS_MIDDLE, false, 2, false>(a, s)
                     : nl == 1 ? launch_one<RA, PASS_MIDDLE, false, 1, false>(a, s)
                               : launch_one<RA, PASS_MIDDLE, false, 0, false>(a, s);
-    case PASS_LAST:
-        if constexpr (RA == 0) return hipErrorInvalidValue;
-        else return launch_one<RA, PASS_LAST, false, 0, SMALL>(a, s);
     }
-    return hipErrorInvalidValue;
-    }
+    if constexpr (FIRST_ONLY) return hipErrorInvalidValue;
+    else return launch_one<RA, PASS_LAST, false, 0, SMALL>(a, s);
 }
 
 hipError_t launch_ntt_pass(const PassArgs& a_in, PassMode mode, bool twist, uint32_t n_batch, hipStream_t s)
