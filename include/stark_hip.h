@@ -306,6 +306,17 @@ int32_t stark_fri_layer_open_many(stark_fri_layers* l, size_t layer, const uint6
  * each, then count c-paths of *next_depth_out digests each. */
 int32_t stark_fri_layer_query(stark_fri_layers* l, size_t layer, const uint64_t* c_indices, size_t count,
                               uint64_t* values_out, uint8_t* paths_out, size_t* depth_out, size_t* next_depth_out);
+
+/* The whole query phase of Fri::prove (fri.rs:229-238: one Fri::query per round) in one round trip.  The
+ * indices of every round follow from the top-level ones (round r asks for top[s] mod len(r)/2), so nothing
+ * has to come back before the next round's reads can be issued.  For each round r < layers-1, in order:
+ * values_out holds 3*count elements [all a | all b | all c] as stark_fri_layer_query gives them for
+ * c_indices[s] = top_indices[s] mod len(r)/2, and paths_out holds [count a-paths | count b-paths] of
+ * depth(r) digests each followed by count c-paths of depth(r+1) digests each, depth(r) = log2 len(r).
+ * values_out: 3*count*(layers-1) elements; paths_out: the sum over r of count*(2*depth(r)+depth(r+1))
+ * digests of 32 bytes. */
+int32_t stark_fri_query_all(stark_fri_layers* l, const uint64_t* top_indices, size_t count, uint64_t* values_out,
+                            uint8_t* paths_out);
 void stark_fri_layers_free(stark_fri_layers* l);
 
 #ifdef __cplusplus

@@ -219,6 +219,7 @@ pub fn fri_commit(fri: &Fri, codeword: Vec<FieldElement>, proof_stream: &mut Pro
 
 /// One round of Fri::query (fri.rs:155-209) answered from the resident layers in one round trip: the
 /// three values and three authentication paths of every colinearity test.
+#[allow(dead_code)]
 fn fri_query_resident(fri: &Fri, l: &Layers, layer: usize, c_indices: &[usize], proof_stream: &mut ProofStream) -> Vec<usize> {
     let t = fri.num_colinearity_tests;
     let cs: Vec<u64> = c_indices.iter().take(t).map(|&i| i as u64).collect();
@@ -251,18 +252,45 @@ fn fri_query_resident(fri: &Fri, l: &Layers, layer: usize, c_indices: &[usize], 
 }
 
 /// Fri::prove (fri.rs:212-254): commit on the device, queries from the retained codewords and trees.
-/// Only the first num_colinearity_tests indices travel from round to round: the list the reference passes
-/// on doubles every round (:160-163,207-208) and only its first entries are ever read (:166-203).
+/// Only the first num_colinearity_tests indices matter from round to round: the list the reference passes
+/// on doubles every round (:160-163,207-208) and only its first entries are ever read (:166-203), so round
+/// i asks for top[s] mod len(i)/2 and the reads of all rounds come back in ONE round trip
+/// (stark_fri_query_all); fri_query_resident above is the same thing one round at a time.
 pub fn fri_prove(fri: &Fri, codeword: Vec<FieldElement>, proof_stream: &mut ProofStream) -> Vec<usize> {
     let l = fri_commit_resident(fri, &codeword, proof_stream);
     let layers = l.count();
-    let top = fri.sample_indices(&proof_stream.prover_fiat_shamir(32), l.len(0) / 2, l.len(layers - 1),
-                                 fri.num_colinearity_tests);
-    let mut indices = top.clone();
-    for i in 0..layers - 1 {
-        let half = l.len(i) / 2;
-        let folded: Vec<usize> = indices.iter().map(|idx| idx % half).collect();
-        indices = fri_query_resident(fri, &l, i, &folded, proof_stream);
+    let t = fri.num_colinearity_tests;
+    let top = fri.sample_indices(&proof_stream.prover_fiat_shamir(32), l.len(0) / 2, l.len(layers - 1), t);
+    if layers > 1 && t > 0 {
+        let depth: Vec<usize> = (0..layers).map(|i| l.len(i).trailing_zeros() as usize).collect();
+        let digests: usize = (0..layers - 1).map(|i| t * (2 * depth[i] + depth[i + 1])).sum();
+        let top64: Vec<u64> = top.iter().take(t).map(|&i| i as u64).collect();
+        let mut values = vec![0u64; 2 * 3 * t * (layers - 1)];
+        let mut paths = vec![0u8; 32 * digests + 32];
+        check(unsafe { stark_fri_query_all(l.0, top64.as_ptr(), t, values.as_mut_ptr(), paths.as_mut_ptr()) });
+        let v = unpack(&values); // per round [all a | all b | all c]
+        let mut at = 0usize;
+        for i in 0..layers - 1 {
+            let e = &v[i * 3 * t..(i + 1) * 3 * t];
+            for s in 0..t {
+                proof_stream.push(
+                    serde_json::to_string(&(e[s].to_string(), e[t + s].to_string(), e[2 * t + s].to_string())).unwrap(),
+                ); // fri.rs:166-179
+            }
+            let path_at = |base: usize, k: usize, d: usize| -> Vec<HashOutput> {
+                paths[32 * (at + base + k * d)..32 * (at + base + (k + 1) * d)]
+                    .chunks_exact(32)
+                    .map(GenericArray::clone_from_slice)
+                    .collect()
+            };
+            for s in 0..t {
+                // fri.rs:182-204: a, b, c paths of test s
+                proof_stream.push(serde_json::to_string(&path_at(0, s, depth[i])).unwrap());
+                proof_stream.push(serde_json::to_string(&path_at(t * depth[i], s, depth[i])).unwrap());
+                proof_stream.push(serde_json::to_string(&path_at(2 * t * depth[i], s, depth[i + 1])).unwrap());
+            }
+            at += t * (2 * depth[i] + depth[i + 1]);
+        }
     }
     let mut out = top.clone();
     out.extend(top.iter().map(|idx| idx + l.len(0) / 2));

@@ -123,6 +123,8 @@ extern "C" {
     pub fn stark_fri_layer_query(l: *mut StarkFriLayers, layer: usize, c_indices: *const u64, count: usize,
                                  values_out: *mut u64, paths_out: *mut u8, depth_out: *mut usize,
                                  next_depth_out: *mut usize) -> i32;
+    pub fn stark_fri_query_all(l: *mut StarkFriLayers, top_indices: *const u64, count: usize, values_out: *mut u64,
+                               paths_out: *mut u8) -> i32;
     pub fn stark_fri_layers_free(l: *mut StarkFriLayers);
 }
 

@@ -1775,6 +1775,62 @@ extern "C" int32_t stark_fri_layer_query(stark_fri_layers* l, size_t layer, cons
     return STARK_OK;
 }
 
+extern "C" int32_t stark_fri_query_all(stark_fri_layers* l, const uint64_t* top_indices, size_t count,
+                                       uint64_t* values_out, uint8_t* paths_out)
+{
+    CtxGuard guard_(l ? l->ctx : nullptr);
+    if (!l || l->len.empty() || !top_indices || !values_out || !paths_out) return fail(STARK_EARG, "null argument");
+    const size_t rounds = l->len.size() - 1;
+    if (count == 0 || rounds == 0) return STARK_OK;
+    if (count > 0x7FFFFFFFull / 3) return fail(STARK_ELENGTH, "too many openings in one call");
+    for (size_t i = 0; i < count; i++)
+        if (top_indices[i] >= l->len[0]) return fail(STARK_EINDEX, "cannot open invalid index");
+    stark_ctx* ctx = l->ctx;
+    // one staging block for all rounds: [indices | values | paths]; one copy in, the launches of every
+    // round back to back, two copies out, one synchronisation
+    size_t path_digests = 0;
+    for (size_t r = 0; r < rounds; r++)
+        path_digests += count * (2 * (size_t)log2_exact(l->len[r]) + (size_t)log2_exact(l->len[r + 1]));
+    const size_t idx_bytes = rounds * 3 * count * sizeof(uint64_t), val_bytes = rounds * 3 * count * sizeof(fe);
+    std::vector<uint64_t> idx(rounds * 3 * count);
+    for (size_t r = 0; r < rounds; r++) {
+        const size_t half = l->len[r] / 2;
+        if (l->len[r + 1] < half) return fail(STARK_ELENGTH, "a layer is shorter than half of the one before");
+        uint64_t* ir = idx.data() + r * 3 * count;
+        for (size_t i = 0; i < count; i++) {
+            const uint64_t c = top_indices[i] % half;
+            ir[i] = c;                           // a
+            ir[count + i] = c + half;            // b (fri.rs:160-163)
+            ir[2 * count + i] = c;               // c, in the next layer
+        }
+    }
+    DevBuf stage(ctx);
+    ST_TRY(stage.alloc(idx_bytes + val_bytes + path_digests * sizeof(digest) + 64));
+    uint64_t* d_idx = (uint64_t*)stage.p;
+    fe* d_val = (fe*)((uint8_t*)stage.p + idx_bytes);
+    digest* d_path = (digest*)((uint8_t*)stage.p + idx_bytes + val_bytes);
+    HIP_TRY(hipMemcpyAsync(d_idx, idx.data(), idx_bytes, hipMemcpyHostToDevice, ctx->stream));
+    size_t at = 0;
+    for (size_t r = 0; r < rounds; r++) {
+        const size_t n = l->len[r], n_next = l->len[r + 1];
+        const int depth = log2_exact(n), depth_next = log2_exact(n_next);
+        const uint64_t* ir = d_idx + r * 3 * count;
+        fe* vr = d_val + r * 3 * count;
+        HIP_TRY(launch_gather_fe(l->cw[r], ir, vr, 2 * count, ctx->stream));
+        HIP_TRY(launch_gather_fe(l->cw[r + 1], ir + 2 * count, vr + 2 * count, count, ctx->stream));
+        HIP_TRY(launch_merkle_open_many(l->tree[r], n, ir, 2 * count, (uint32_t)depth, d_path + at, ctx->stream));
+        at += 2 * count * (size_t)depth;
+        HIP_TRY(launch_merkle_open_many(l->tree[r + 1], n_next, ir + 2 * count, count, (uint32_t)depth_next, d_path + at,
+                                        ctx->stream));
+        at += count * (size_t)depth_next;
+    }
+    HIP_TRY(hipMemcpyAsync(values_out, d_val, val_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (path_digests)
+        HIP_TRY(hipMemcpyAsync(paths_out, d_path, path_digests * sizeof(digest), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return STARK_OK;
+}
+
 extern "C" void stark_fri_layers_free(stark_fri_layers* l)
 {
     CtxGuard guard_(l ? l->ctx : nullptr);

@@ -158,6 +158,28 @@ class FriLayers:
             return [[paths[base + j * depth + k].tobytes() for k in range(depth)] for j in range(t)]
         return vals[:, :t], cut(0, d), cut(t * d, d), cut(2 * t * d, dn)
 
+    def query_all(self, top_indices: Sequence[int]):
+        """Every round of Fri::prove's query phase in one round trip: a list, one entry per round, of what
+        query(i, [t % (len_i / 2) for t in top_indices]) returns."""
+        idx = np.asarray(list(top_indices), dtype=np.uint64)
+        t, rounds = len(idx), len(self) - 1
+        if t == 0 or rounds <= 0:
+            return []
+        depth = [int(self.layer_len(i)).bit_length() - 1 for i in range(rounds + 1)]
+        digests = sum(t * (2 * depth[i] + depth[i + 1]) for i in range(rounds))
+        vals = np.empty((rounds, 3, t, 2), dtype=np.uint64)
+        paths = np.empty((max(digests, 1), 32), dtype=np.uint8)
+        self.ctx._chk(self.ctx.lib.stark_fri_query_all(self.h, idx.ctypes.data, t, vals.ctypes.data, paths.ctypes.data))
+        out, at = [], 0
+        for i in range(rounds):
+            d, dn = depth[i], depth[i + 1]
+
+            def cut(base, dd):
+                return [[paths[at + base + j * dd + k].tobytes() for k in range(dd)] for j in range(t)]
+            out.append((vals[i], cut(0, d), cut(t * d, d), cut(2 * t * d, dn)))
+            at += t * (2 * d + dn)
+        return out
+
     def free(self):
         if self.h and self.ctx.h:
             self.ctx.lib.stark_fri_layers_free(self.h)

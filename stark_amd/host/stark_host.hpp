@@ -997,16 +997,41 @@ struct Fri {
         size_t layers = stark_fri_layers_count(h->l);
         std::vector<size_t> top = sample_indices(ps.prover_fiat_shamir(32), stark_fri_layer_len(h->l, 0) / 2,
                                                  stark_fri_layer_len(h->l, layers - 1), num_colinearity_tests);
-        std::vector<size_t> indices = top;
-        for (size_t i = 0; i + 1 < layers; i++) {
-            size_t half = stark_fri_layer_len(h->l, i) / 2;
-            for (size_t& idx : indices) idx %= half;
-            // query() returns a and b for EVERY index it was given, so the reference's list doubles
-            // each round (fri.rs:160-163,207-208) although only its first num_colinearity_tests
-            // entries are ever read (:166-203); keeping just those gives the same stream without
-            // a list of t * 2^rounds entries
-            if (indices.size() > num_colinearity_tests) indices.resize(num_colinearity_tests);
-            indices = query_device(h->l, i, indices, ps);
+        // Fri::query per round (fri.rs:229-238).  query() returns a and b for EVERY index it was given, so the
+        // reference's list doubles each round (:160-163,207-208) although only its first num_colinearity_tests
+        // entries are ever read (:166-203): round i reads top[s] mod len(i)/2.  All rounds' reads are therefore
+        // known now and come back in one round trip; the pushes keep the reference's order.
+        const size_t t = num_colinearity_tests;
+        if (layers > 1 && t > 0) {
+            std::vector<uint64_t> top64(top.begin(), top.begin() + t), vals((layers - 1) * 6 * t);
+            size_t digests = 0;
+            std::vector<size_t> depth(layers);
+            for (size_t i = 0; i < layers; i++) {
+                size_t len = stark_fri_layer_len(h->l, i), d = 0;
+                while (((size_t)1 << d) < len) d++;
+                depth[i] = d;
+            }
+            for (size_t i = 0; i + 1 < layers; i++) digests += t * (2 * depth[i] + depth[i + 1]);
+            std::vector<uint8_t> raw(32 * digests + 32);
+            check(stark_fri_query_all(h->l, top64.data(), t, vals.data(), raw.data()));
+            std::vector<FieldElement> e = unpack(vals);
+            size_t at = 0;
+            for (size_t i = 0; i + 1 < layers; i++) {
+                const FieldElement* er = e.data() + i * 3 * t;
+                for (size_t s = 0; s < t; s++)                                                   // :166-179
+                    ps.push(wire::json_string_triple(er[s].to_string(), er[t + s].to_string(), er[2 * t + s].to_string()));
+                auto path_at = [&](size_t base, size_t d, size_t s) {
+                    std::vector<HashOutput> p(d);
+                    for (size_t k = 0; k < d; k++) std::memcpy(p[k].data(), raw.data() + 32 * (at + base + s * d + k), 32);
+                    return p;
+                };
+                for (size_t s = 0; s < t; s++) {                                                 // :182-204
+                    ps.push(wire::json_hash_path(path_at(0, depth[i], s)));
+                    ps.push(wire::json_hash_path(path_at(t * depth[i], depth[i], s)));
+                    ps.push(wire::json_hash_path(path_at(2 * t * depth[i], depth[i + 1], s)));
+                }
+                at += t * (2 * depth[i] + depth[i + 1]);
+            }
         }
         std::vector<size_t> out = top;
         for (size_t idx : top) out.push_back(idx + stark_fri_layer_len(h->l, 0) / 2);

@@ -85,9 +85,9 @@ class Stream:
         self.h = None
         self.h = _vp(handle) if handle else _vp(lib.sh_ps_new())
 
-    def __del__(self):
-        if getattr(self, "h", None):
-            lib.sh_ps_free(self.h)
+    def __del__(self, _lib=lib):                 # the module's globals may be gone when the interpreter shuts down
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.sh_ps_free(self.h)
             self.h = None
 
     def push(self, s):

@@ -758,6 +758,26 @@ def test_fri_layer_query_equals_reads_and_opens(ctx):
     layers.free()
 
 
+@pytest.mark.parametrize("log_n,ncol", [(12, 3), (8, 17), (16, 5)])
+def test_fri_query_all_equals_round_by_round(ctx, log_n, ncol):
+    """The whole query phase of Fri::prove in one round trip (fri.rs:229-238) against one query per round
+    with the indices reduced as the reference reduces them."""
+    from stark_amd import StarkError
+    n = 1 << log_n
+    x = oc.splitmix(n, 99 + log_n)
+    layers = ctx.fri_commit(x, G, so.primitive_nth_root(n), 4, ncol, lambda r, last, root: None if last else 5 + 3 * r)
+    top = [0, n // 2 - 1, 12345 % (n // 2), (n // 3) | 1, 1]
+    got = layers.query_all(top)
+    assert len(got) == len(layers) - 1
+    for i, (vals, pa, pb, pc) in enumerate(got):
+        cs = [t % (layers.layer_len(i) // 2) for t in top]
+        v1, a1, b1, c1 = layers.query(i, cs)
+        assert np.array_equal(vals, v1) and pa == a1 and pb == b1 and pc == c1
+    with pytest.raises(StarkError, match="cannot open invalid index"):
+        layers.query_all([n])
+    layers.free()
+
+
 @pytest.mark.parametrize("log_n", [12, 16, 22])
 def test_ntt_structured_inputs(ctx, log_n):
     """Inputs whose transforms are full of 0, p-1 and exact multiples of p before
