@@ -147,6 +147,12 @@ int32_t stark_mpoly_eval_dev(stark_ctx* ctx, size_t n_vars, const uint64_t* cons
  * (*is_zero_out, if not NULL, tells the two apart).  Synchronises. */
 int32_t stark_poly_degree_dev(stark_ctx* ctx, const uint64_t* coeffs_dev, size_t n, size_t* degree_out,
                               int32_t* is_zero_out);
+/* Polynomial::eval (univariate_poly.rs:87-96) of n_polys polynomials of n coefficients each (lowest degree
+ * first, polynomial q at coeffs_dev + 2*q*stride words) at n_points <= 16 points given on the host:
+ * out[q * n_points + p] = polynomial q at points[p] (host memory).  The verifier's evaluations of long
+ * public polynomials at the opened points.  Synchronises. */
+int32_t stark_poly_eval_points_dev(stark_ctx* ctx, const uint64_t* coeffs_dev, size_t n, size_t n_polys, size_t stride,
+                                   const uint64_t* points, size_t n_points, uint64_t* out);
 /* FieldElement::sample (field.rs:110-116) of n byte strings of `width` bytes
  * lying back to back in device memory (the randomizer coefficients of
  * stark.rs:345-351 from their raw random bytes).  String i lands at out[i], or

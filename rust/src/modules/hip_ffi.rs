@@ -67,6 +67,8 @@ extern "C" {
                                 mul_dev: *const u64, out_dev: *mut u64, n: usize) -> i32;
     pub fn stark_poly_degree_dev(ctx: *mut StarkCtx, coeffs_dev: *const u64, n: usize, degree_out: *mut usize,
                                  is_zero_out: *mut i32) -> i32;
+    pub fn stark_poly_eval_points_dev(ctx: *mut StarkCtx, coeffs_dev: *const u64, n: usize, n_polys: usize, stride: usize,
+                                      points: *const u64, n_points: usize, out: *mut u64) -> i32;
     pub fn stark_sample_bytes_dev(ctx: *mut StarkCtx, bytes_dev: *const u8, width: usize, n: usize, reversed: i32,
                                   out_dev: *mut u64) -> i32;
     pub fn stark_fourstep_twiddle_dev(ctx: *mut StarkCtx, data_dev: *mut u64, n_total: usize, row_start: usize,

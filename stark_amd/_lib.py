@@ -78,6 +78,7 @@ SIGNATURES = {
     "stark_fri_layer_open": (i32, [C.c_void_p, sz, sz, u8p, szp]),
     "stark_fri_layer_open_many": (i32, [C.c_void_p, sz, C.c_void_p, sz, C.c_void_p, szp]),
     "stark_fri_layer_query": (i32, [C.c_void_p, sz, C.c_void_p, sz, C.c_void_p, C.c_void_p, szp, szp]),
+    "stark_poly_eval_points_dev": (i32, [C.c_void_p, C.c_void_p, sz, sz, sz, C.c_void_p, sz, C.c_void_p]),
     "stark_fri_query_all": (i32, [C.c_void_p, C.c_void_p, sz, C.c_void_p, C.c_void_p]),
     "stark_fri_layers_free": (None, [C.c_void_p]),
 }

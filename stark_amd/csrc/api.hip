@@ -1250,6 +1250,60 @@ extern "C" int32_t stark_poly_degree_dev(stark_ctx* ctx, const uint64_t* coeffs_
     return STARK_OK;
 }
 
+extern "C" int32_t stark_poly_eval_points_dev(stark_ctx* ctx, const uint64_t* coeffs_dev, size_t n, size_t n_polys,
+                                              size_t stride, const uint64_t* points, size_t n_points, uint64_t* out)
+{
+    CtxGuard guard_(ctx);
+    if (!ctx || (n && n_polys && !coeffs_dev) || (n_points && (!points || !out))) return fail(STARK_EARG, "null argument");
+    if (n_points > EVAL_MAX_POINTS) return fail(STARK_ELENGTH, "at most 16 points in one call");
+    if (n_polys > 65535) return fail(STARK_ELENGTH, "too many polynomials in one call");
+    if (n_polys > 1 && stride < n) return fail(STARK_ELENGTH, "stride shorter than the polynomial");
+    if (n_points == 0 || n_polys == 0) return STARK_OK;
+    const HostField& F = ctx->F;
+    if (n == 0) {                                             // the zero polynomial (univariate_poly.rs:87-96 returns zero)
+        memset(out, 0, n_polys * n_points * sizeof(fe));
+        return STARK_OK;
+    }
+    EvalArgs a{};
+    a.coeffs = (const fe*)coeffs_dev;
+    a.n = n;
+    a.stride = stride;
+    a.n_points = (uint32_t)n_points;
+    const size_t blocks = (n + EVAL_BLOCK_COEFFS - 1) / EVAL_BLOCK_COEFFS;
+    if (blocks > 0x7fffffffull) return fail(STARK_ETOOLARGE, "polynomial too long");
+    a.n_blocks = (uint32_t)blocks;
+    std::vector<fe> x4096(n_points);
+    for (size_t p = 0; p < n_points; p++) {
+        fe x{points[2 * p], points[2 * p + 1]};
+        if (!is_canonical(x)) return fail(STARK_EARG, "point not reduced modulo p");
+        a.x_m[p] = F.to_mont(x);
+        fe pw = F.pow(x, 16);
+        for (int k = 0; k < 8; k++) {
+            a.x_pow_m[p][k] = F.to_mont(pw);
+            pw = F.mul(pw, pw);
+        }
+        x4096[p] = pw;                                        // x^(16 * 2^8)
+    }
+    const size_t n_part = n_polys * blocks * n_points;
+    DevBuf part(ctx);
+    ST_TRY(part.alloc(n_part * sizeof(fe)));
+    a.partial = (fe*)part.p;
+    HIP_TRY(launch_poly_eval_points(a, (uint32_t)n_polys, ctx->stream));
+    std::vector<fe> host(n_part);
+    HIP_TRY(hipMemcpyAsync(host.data(), part.p, n_part * sizeof(fe), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    // the blocks are the coefficients of a polynomial in x^4096: Horner on the host
+    for (size_t q = 0; q < n_polys; q++)
+        for (size_t p = 0; p < n_points; p++) {
+            const fe ym = F.to_mont(x4096[p]);
+            fe acc = fe_zero();
+            for (size_t b = blocks; b-- > 0;) acc = fe_add(mont_mul(acc, ym), host[(q * blocks + b) * n_points + p]);
+            out[2 * (q * n_points + p)] = acc.lo;
+            out[2 * (q * n_points + p) + 1] = acc.hi;
+        }
+    return STARK_OK;
+}
+
 extern "C" int32_t stark_sample_bytes_dev(stark_ctx* ctx, const uint8_t* bytes_dev, size_t width, size_t n,
                                           int32_t reversed, uint64_t* out_dev)
 {

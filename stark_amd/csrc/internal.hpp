@@ -150,6 +150,20 @@ struct LincombArgs {
 };
 hipError_t launch_lincomb(const LincombArgs& a, hipStream_t s);
 
+// Polynomial::eval (univariate_poly.rs:87-96) of several polynomials at a few points: workgroup b of
+// polynomial q reduces its 4096 coefficients to sum_j c[4096 b + j] x^j for every point x.
+constexpr uint32_t EVAL_MAX_POINTS = 16;
+constexpr uint32_t EVAL_BLOCK_COEFFS = 4096;
+struct EvalArgs {
+    const fe* coeffs;                    // polynomial q at coeffs + q * stride, lowest degree first
+    uint64_t n, stride;
+    fe* partial;                         // [q][block][point]
+    uint32_t n_points, n_blocks;
+    fe x_m[EVAL_MAX_POINTS];             // the points, Montgomery form
+    fe x_pow_m[EVAL_MAX_POINTS][8];      // x^(16 * 2^k), k < 8, Montgomery form
+};
+hipError_t launch_poly_eval_points(const EvalArgs& a, uint32_t n_polys, hipStream_t s);
+
 constexpr uint32_t MPOLY_MAX_VARS = 16;
 struct MPolyArgs {
     const fe* cols[MPOLY_MAX_VARS];      // variable v at point i: cols[v][(i + rot[v]) mod n]

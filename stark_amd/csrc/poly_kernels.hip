@@ -186,6 +186,44 @@ hipError_t launch_mpoly_eval(const MPolyArgs& a, hipStream_t s)
     return hipGetLastError();
 }
 
+// Polynomial::eval at a few points.  A thread evaluates its strip of 16 coefficients by Horner for every
+// point (the coefficients are loaded once), the strips of a workgroup are then combined pairwise through
+// LDS with the powers x^(16 * 2^k); what leaves the workgroup is the value of its 4096-coefficient block
+// as a polynomial of its own, and the caller combines the blocks with powers of x^4096.
+__global__ __launch_bounds__(256) void poly_eval_points_kernel(EvalArgs a)
+{
+    __shared__ fe s[256];
+    const uint32_t t = threadIdx.x;
+    const fe* __restrict__ c = a.coeffs + (uint64_t)blockIdx.y * a.stride;
+    const uint64_t base = (uint64_t)blockIdx.x * EVAL_BLOCK_COEFFS + 16ull * t;
+    fe strip[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) strip[j] = base + j < a.n ? c[base + j] : fe_zero();
+    for (uint32_t p = 0; p < a.n_points; p++) {
+        const fe x = a.x_m[p];
+        fe acc = strip[15];
+#pragma unroll
+        for (int j = 14; j >= 0; j--) acc = fe_add(mont_mul(acc, x), strip[j]);
+        s[t] = acc;
+        __syncthreads();
+        for (uint32_t k = 0; k < 8; k++) {
+            const uint32_t step = 1u << k;
+            if ((t & (2 * step - 1)) == 0) s[t] = fe_add(s[t], mont_mul(s[t + step], a.x_pow_m[p][k]));
+            __syncthreads();
+        }
+        if (t == 0) a.partial[((uint64_t)blockIdx.y * a.n_blocks + blockIdx.x) * a.n_points + p] = s[0];
+        __syncthreads();
+    }
+}
+
+hipError_t launch_poly_eval_points(const EvalArgs& a, uint32_t n_polys, hipStream_t s)
+{
+    if (a.n == 0 || n_polys == 0 || a.n_points == 0) return hipSuccess;
+    if (a.n_points > EVAL_MAX_POINTS || n_polys > 65535) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(poly_eval_points_kernel, dim3(a.n_blocks, n_polys), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
 // Polynomial::degree (univariate_poly.rs:69-85) of a coefficient vector, lowest
 // degree first: *result = 1 + the largest index holding a nonzero coefficient,
 // 0 when there is none.  *result must be zero before the launch.

@@ -330,6 +330,17 @@ class Context:
     def sample_bytes_dev(self, bytes_ptr, width: int, n: int, out_ptr, reversed_: bool = False):
         self._chk(self.lib.stark_sample_bytes_dev(self.h, _ptr(bytes_ptr), width, n, int(reversed_), _ptr(out_ptr)))
 
+    def poly_eval_points_dev(self, coeffs_ptr, n: int, points: Sequence[int], n_polys: int = 1,
+                             stride: Optional[int] = None) -> List[List[int]]:
+        """Polynomial::eval of n_polys resident polynomials (n coefficients each, lowest first) at up to 16
+        points: result[q][p]."""
+        pts = np.array([[x & ((1 << 64) - 1), x >> 64] for x in points], dtype=np.uint64).reshape(-1, 2)
+        out = np.zeros((max(n_polys * len(points), 1), 2), dtype=np.uint64)
+        self._chk(self.lib.stark_poly_eval_points_dev(self.h, _ptr(coeffs_ptr), n, n_polys, stride or n, pts.ctypes.data,
+                                                      len(points), out.ctypes.data))
+        vals = [int(out[i, 0]) | (int(out[i, 1]) << 64) for i in range(n_polys * len(points))]
+        return [vals[q * len(points):(q + 1) * len(points)] for q in range(n_polys)]
+
     def vec_mul(self, a, b) -> np.ndarray:
         a, b = _as_fe_array(a), _as_fe_array(b)
         assert a.shape == b.shape

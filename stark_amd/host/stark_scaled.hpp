@@ -661,48 +661,58 @@ struct ScaledStark {
             std::vector<HashOutput> path = wire::json_hash_path_parse(ps.pull());
             if (!Merkle::verify(root_of(randomizer_root), i, path, wire::bincode_field_element(leaf))) return false;
         }
-        // the constant columns' polynomials, coefficients lowest first
         const size_t steps = original_trace_length - 1, K = constant_columns.size();
-        std::vector<FieldElement> constants;
-        if (K) constants = constant_polynomials(constant_columns)->download(0, K * steps);
         const size_t max_deg = max_degree(air);
         std::vector<size_t> tq_bounds = transition_quotient_degree_bounds(air);
         std::vector<size_t> bq_bounds = boundary_quotient_degree_bounds(randomized_trace_length, boundary);
         const starkf::HostField& F = host_field();
-        // The long evaluations first, side by side on a few threads: at every opened point the K constant
-        // polynomials (Horner over T - 1 coefficients) and the transition zeroifier as the product it is
-        // (:666, one factor per trace point).
+        // The long evaluations.  At every opened point: the K constant columns' polynomials (T - 1
+        // coefficients each), interpolated and evaluated on the device, from which only the values come back;
+        // and the transition zeroifier as the product it is (:666, one factor per trace point), cut into runs
+        // of consecutive factors that a few threads multiply up side by side.
         std::vector<FieldElement> xs;
         for (size_t idx : indices) xs.push_back(generator * omega.pow(idx));
         std::vector<FieldElement> constant_values(indices.size() * K), tz_values(indices.size());
+        if (K && !indices.empty()) {
+            if (indices.size() > 16) throw Panic("more opened points than one evaluation call takes");
+            std::unique_ptr<DeviceVector> polys = constant_polynomials(constant_columns);
+            std::vector<uint64_t> pts(2 * xs.size()), vals(2 * K * xs.size());
+            for (size_t i = 0; i < xs.size(); i++) fe_words(xs[i], &pts[2 * i]);
+            check(stark_poly_eval_points_dev(context(), polys->words(), steps, K, steps, pts.data(), xs.size(), vals.data()));
+            for (size_t k = 0; k < K; k++)
+                for (size_t i = 0; i < xs.size(); i++) {
+                    starkf::fe v{vals[2 * (k * xs.size() + i)], vals[2 * (k * xs.size() + i) + 1]};
+                    constant_values[i * K + k] = FieldElement::wrap(v);
+                }
+        }
         {
-            const size_t tasks = indices.size() * (K + 1);
+            const size_t factors = original_trace_length - 1;
+            const size_t runs = factors >= ((size_t)1 << 14) ? 8 : 1, per = (factors + runs - 1) / runs;
+            const size_t tasks = indices.size() * runs;
+            std::vector<starkf::fe> part(tasks, F.one_m);
             std::atomic<size_t> next{0};
+            const starkf::fe om = F.to_mont(omicron.raw());
             auto work = [&] {
                 for (size_t task = next++; task < tasks; task = next++) {
-                    const size_t i = task / (K + 1), k = task % (K + 1);
+                    const size_t i = task / runs, lo = (task % runs) * per, hi = std::min(factors, lo + per);
                     const starkf::fe xm = F.to_mont(xs[i].raw());
-                    if (k < K) {
-                        starkf::fe acc{0, 0};
-                        const FieldElement* c = constants.data() + k * steps;
-                        for (size_t j = steps; j-- > 0;) acc = starkf::fe_add(starkf::mont_mul(acc, xm), c[j].raw());
-                        constant_values[i * K + k] = FieldElement::wrap(acc);
-                    } else {
-                        starkf::fe tz = F.one_m, w = F.one_m;
-                        const starkf::fe om = F.to_mont(omicron.raw());
-                        for (size_t j = 0; j + 1 < original_trace_length; j++) {
-                            tz = starkf::mont_mul(tz, starkf::fe_sub(xm, w));
-                            w = starkf::mont_mul(w, om);
-                        }
-                        tz_values[i] = FieldElement::wrap(F.from_mont(tz));
+                    starkf::fe tz = F.one_m, w = F.to_mont(omicron.pow(lo).raw());
+                    for (size_t j = lo; j < hi; j++) {
+                        tz = starkf::mont_mul(tz, starkf::fe_sub(xm, w));
+                        w = starkf::mont_mul(w, om);
                     }
+                    part[task] = tz;
                 }
             };
-            const size_t workers = original_trace_length >= ((size_t)1 << 14) ? std::min<size_t>(8, tasks) : 1;
             std::vector<std::thread> pool;
-            for (size_t w = 1; w < workers; w++) pool.emplace_back(work);
+            for (size_t w = 1; w < std::min<size_t>(8, tasks); w++) pool.emplace_back(work);
             work();
             for (auto& th : pool) th.join();
+            for (size_t i = 0; i < indices.size(); i++) {
+                starkf::fe tz = F.one_m;
+                for (size_t r = 0; r < runs; r++) tz = starkf::mont_mul(tz, part[i * runs + r]);
+                tz_values[i] = FieldElement::wrap(F.from_mont(tz));
+            }
         }
         for (size_t i = 0; i < indices.size(); i++) {                                        // :589-719
             size_t current_index = indices[i];

@@ -193,6 +193,29 @@ def test_poly_degree(ctx):
     assert ctx.poly_degree_dev(_dev(x), 40001) == (40000, False)
 
 
+@pytest.mark.parametrize("n,polys,pad", [(1, 1, 0), (15, 2, 3), (16, 1, 0), (4096, 3, 0), (4097, 2, 1), (100000, 2, 7),
+                                         (1 << 20, 1, 0)])
+def test_poly_eval_points(ctx, n, polys, pad):
+    """Polynomial::eval (univariate_poly.rs:87-96) of resident polynomials at a few points, against Horner
+    on Python integers."""
+    from stark_amd import StarkError
+    stride = n + pad
+    c = oc.splitmix(stride * polys, 60 + n % 97).reshape(polys, stride, 2)
+    points = [0, 1, P - 1, G, 123456789, pow(G, 77, P)]
+    got = ctx.poly_eval_points_dev(_dev(c), n, points, n_polys=polys, stride=stride)
+    for q in range(polys):
+        coeffs = oc.to_ints(np.ascontiguousarray(c[q, :n]))
+        for k, x in enumerate(points):
+            acc = 0
+            for v in reversed(coeffs):
+                acc = (acc * x + v) % P
+            assert got[q][k] == acc, (q, k)
+    with pytest.raises(StarkError, match="at most 16 points"):
+        ctx.poly_eval_points_dev(_dev(c), n, list(range(17)), n_polys=polys, stride=stride)
+    with pytest.raises(StarkError, match="not reduced"):
+        ctx.poly_eval_points_dev(_dev(c), n, [P], n_polys=polys, stride=stride)
+
+
 @pytest.mark.parametrize("width,n", [(17, 1000), (32, 257), (1, 5), (40, 64)])
 def test_sample_bytes(ctx, width, n):
     """FieldElement::sample (field.rs:110-116) of n byte strings; reversed as Polynomial::coeffs is filled."""
