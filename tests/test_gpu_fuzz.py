@@ -104,3 +104,38 @@ def test_random_trees_and_folds(ctx):
             alpha, omega = rng.randrange(P), pow(G, (1 << 119) >> log_n, P)
             offset = rng.choice([G, 1, rng.randrange(1, P)])
             assert np.array_equal(ctx.fri_fold(x, alpha, offset, omega), oc.fri_fold(x, alpha, offset, omega)), (case, log_n)
+
+
+def test_repeated_calls_do_not_grow_device_memory():
+    """The context's caches are bounded: after a first round of calls has built every table and filled the
+    block cache, a few hundred more rounds of the same calls leave the device's free memory where it was."""
+    import torch
+    from stark_amd import Context
+    c = Context(0)
+    try:
+        n = 1 << 14
+        x = oc.splitmix(n, 3)
+        omega = pow(G, (1 << 119) >> 14, P)
+
+        def one_round(k):
+            f = c.ntt(x)
+            c.ntt(f, inverse=True)
+            cw = c.coset_lde_batch(x[: n // 4], n, G if k % 2 else 3 + k % 5)[0]     # a few distinct offsets
+            root, tree = c.merkle_commit_fe(cw, keep_tree=True)
+            tree.open(k % n)
+            tree.free()
+            layers = c.fri_commit(cw, G, omega, 4, 5, lambda r, last, rt: None if last else 7 + r)
+            layers.query_all([1, 2, 3])
+            layers.free()
+
+        for k in range(12):
+            one_round(k)
+        torch.cuda.synchronize()
+        free_before = torch.cuda.mem_get_info()[0]
+        for k in range(300):
+            one_round(k)
+        torch.cuda.synchronize()
+        free_after = torch.cuda.mem_get_info()[0]
+        assert free_before - free_after < (64 << 20), (free_before, free_after)
+    finally:
+        c.close()
