@@ -413,3 +413,24 @@ def test_prover_refuses_what_it_cannot_prove(hm):
             job.prove(random)
     finally:
         job.free()
+
+
+def test_repeated_proofs_do_not_grow_device_memory(hm):
+    """Every device vector of a proof goes back to the context's block cache: after the first proofs, more
+    proofs and verifications of the same size leave the device's free memory where it was."""
+    import torch
+    job = _Chain(hm, 77, 1 << 10)
+    try:
+        random = hashlib.shake_256(b"again").digest(job.random_bytes)
+        for _ in range(3):
+            proof, _ = job.prove(random)
+        torch.cuda.synchronize()
+        free_before = torch.cuda.mem_get_info()[0]
+        for _ in range(40):
+            again, _ = job.prove(random)
+            assert again == proof
+            assert job.verify(job.output, again) == 1
+        torch.cuda.synchronize()
+        assert free_before - torch.cuda.mem_get_info()[0] < (64 << 20)
+    finally:
+        job.free()
