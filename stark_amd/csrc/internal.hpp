@@ -17,9 +17,7 @@ using starkh::digest;
 
 constexpr int TILE_ELEMS = 4096;      // elements per workgroup tile
 constexpr int TILE_THREADS = 256;
-constexpr int SMALL_MAX_LOG = 12;     // n <= 4096 fits one workgroup's LDS (ntt_small_kernel)
-constexpr int PASS_MIN_LOG = 10;      // from n = 1024 on the tiled multi-pass kernels are faster (two passes of 2^5 or
-                                      // 2^6; below 4096 points several transforms of a batch share a tile)
+constexpr int SMALL_MAX_LOG = 8;      // the single-workgroup kernel (ntt_small_kernel) serves n < 32 and coset or padded n <= 256
 constexpr int SHORT_MIN_LOG = 5;      // 32 .. 256 points: one pass (a tile spans 4096 / n transforms); 512: radix 16 then 32
 constexpr int MAX_PASSES = 4;
 
