@@ -686,8 +686,10 @@ static int32_t tree_build(stark_ctx* ctx, const fe* elems_dev, size_t n, uint8_t
     void* d = nullptr;
     ST_TRY(pool_alloc(ctx, bytes, &d));
     digest* tree = (digest*)d;
-    hipError_t e = launch_leaf_hash(elems_dev, tree, n, ctx->stream);
-    if (e == hipSuccess) e = launch_merkle_reduce(tree, n, ctx->stream);
+    digest* level = tree;
+    size_t m = n;
+    hipError_t e = launch_leaf_levels(elems_dev, n, nullptr, tree, (uint32_t)log2_exact(n), 1, ctx->stream, &level, &m);
+    if (e == hipSuccess) e = launch_merkle_reduce(level, m, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(ctx->pinned, tree + (2 * n - 2), 32, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) {
@@ -722,9 +724,11 @@ static int32_t roots_batch(stark_ctx* ctx, const uint64_t* elems_dev, size_t n, 
     for (size_t c0 = 0; c0 < n_cols; c0 += group) {
         const size_t g = n_cols - c0 < group ? n_cols - c0 : group;
         digest* roots_dev = nullptr;
-        HIP_TRY(launch_leaf_hash_batch((const fe*)elems_dev + c0 * col_stride, col_stride, level0, (uint32_t)log_n, g,
-                                       ctx->stream));
-        HIP_TRY(launch_merkle_reduce(level0, g * n, ctx->stream, nullptr, g, &roots_dev));
+        digest* level = level0;
+        size_t m = g * n;
+        HIP_TRY(launch_leaf_levels((const fe*)elems_dev + c0 * col_stride, col_stride, nullptr, level0, (uint32_t)log_n, g,
+                                   ctx->stream, &level, &m));
+        HIP_TRY(launch_merkle_reduce(level, m, ctx->stream, nullptr, g, &roots_dev));
         HIP_TRY(hipMemcpyAsync(roots_out + 32 * c0, roots_dev, 32 * g,
                                out_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
         if (!out_is_device) HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -754,8 +758,11 @@ extern "C" int32_t stark_merkle_subtree_roots_dev(stark_ctx* ctx, const uint64_t
     void* d = nullptr;
     ST_TRY(pool_alloc(ctx, bytes, &d));
     digest* roots = nullptr;
-    hipError_t e = launch_leaf_hash_batch((const fe*)elems_dev, chunk_len, (digest*)d, (uint32_t)log_c, n_chunks, ctx->stream);
-    if (e == hipSuccess) e = launch_merkle_reduce((digest*)d, total, ctx->stream, nullptr, n_chunks, &roots);
+    digest* level = (digest*)d;
+    size_t m = total;
+    hipError_t e = launch_leaf_levels((const fe*)elems_dev, chunk_len, nullptr, (digest*)d, (uint32_t)log_c, n_chunks,
+                                      ctx->stream, &level, &m);
+    if (e == hipSuccess) e = launch_merkle_reduce(level, m, ctx->stream, nullptr, n_chunks, &roots);
     if (e == hipSuccess)
         e = hipMemcpyAsync(roots_dev_out, roots, n_chunks * sizeof(digest), hipMemcpyDeviceToDevice, ctx->stream);
     if (e != hipSuccess) {
@@ -1396,8 +1403,10 @@ extern "C" int32_t stark_merkle_root_fe_static_dev(stark_ctx* ctx, const uint64_
         return STARK_OK;
     }
     digest* tree = (digest*)ctx->static_scratch;   // every level is written in full before it is read: nothing to clear
-    HIP_TRY(launch_leaf_hash((const fe*)elems_dev, tree, n, ctx->stream));
-    HIP_TRY(launch_merkle_reduce(tree, n, ctx->stream, (digest*)root_dev_out));
+    digest* level = tree;
+    size_t m = n;
+    HIP_TRY(launch_leaf_levels((const fe*)elems_dev, n, nullptr, tree, (uint32_t)log2_exact(n), 1, ctx->stream, &level, &m));
+    HIP_TRY(launch_merkle_reduce(level, m, ctx->stream, (digest*)root_dev_out));
     return STARK_OK;
 }
 
@@ -1673,9 +1682,14 @@ static int32_t fri_commit_impl(stark_ctx* ctx, const fe* cw_src, bool src_is_hos
     // Roots arrive through host-mapped pinned memory, written by the kernel that
     // produces them; a one-leaf layer has no such kernel and is copied instead.
     digest* root_mail = (digest*)((uint8_t*)ctx->pinned + 2048);
-    if (src_is_host) FRI_HIP(launch_leaf_hash(L->cw[0], L->tree[0], N, ctx->stream));
-    else FRI_HIP(launch_leaf_hash_copy(cw_src, L->cw[0], L->tree[0], N, ctx->stream));   // device source: copy in the hash pass
-    FRI_HIP(launch_merkle_reduce(L->tree[0], N, ctx->stream, root_mail));                                  // fri.rs:119
+    {
+        digest* level = L->tree[0];
+        size_t m = N;
+        const uint32_t log_N = (uint32_t)log2_exact(N);
+        if (src_is_host) FRI_HIP(launch_leaf_levels(L->cw[0], N, nullptr, L->tree[0], log_N, 1, ctx->stream, &level, &m));
+        else FRI_HIP(launch_leaf_levels(cw_src, N, L->cw[0], L->tree[0], log_N, 1, ctx->stream, &level, &m));   // device source: copy in the hash pass
+        FRI_HIP(launch_merkle_reduce(level, m, ctx->stream, root_mail));                                   // fri.rs:119
+    }
     // 2^-1 alpha offset_r^-1 per round: the two inverses are taken once (a Fermat inverse is ~400
     // host multiplications) and offset_r^-1 = (offset^-1)^(2^r) follows by squaring (fri.rs:142)
     const fe two_inv = F.inverse(fe{2, 0});

@@ -92,6 +92,8 @@ hipError_t launch_leaf_hash_bytes(const uint8_t* flat, const uint64_t* offsets, 
                                   hipStream_t s);
 // Reduce a level of m digests (power of two) to the root, writing every level
 // contiguously after it.
+hipError_t launch_leaf_levels(const fe* elems, size_t col_stride, fe* copy, digest* tree, uint32_t log_n, size_t n_cols,
+                              hipStream_t s, digest** level_out, size_t* m_out);
 hipError_t launch_leaf_hash_batch(const fe* elems, size_t col_stride, digest* level0, uint32_t log_n, size_t n_cols,
                                   hipStream_t s);
 // `level` holds n_trees trees side by side; root_out, if not null (single tree only), also receives
