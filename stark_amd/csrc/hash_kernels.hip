@@ -461,6 +461,47 @@ hipError_t launch_fri_fold(const FoldArgs& a, hipStream_t s)
     return hipGetLastError();
 }
 
+// Fold, leaf digests and the two tree levels above them in one pass: leaf_subtree_kernel with the leaves
+// produced by the fold instead of loaded (a wave owns 256 consecutive outputs; a.half is a multiple of 256).
+__global__ __launch_bounds__(256) void fri_fold_subtree_kernel(FoldArgs a)
+{
+    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t lane = threadIdx.x & 63;
+    if (wave * 256 >= a.half) return;                          // whole waves leave together
+    const size_t first = wave * 256;
+    digest* __restrict__ level1 = a.leaf_out + a.half;
+    digest* __restrict__ level2 = level1 + a.half / 2;
+    digest pa{}, pb{};
+#pragma clang loop unroll(disable)
+    for (int k = 0; k < 2; k++) {
+        digest da{}, db{};
+#pragma clang loop unroll(disable)
+        for (int h = 0; h < 2; h++) {
+            const size_t i = first + 128 * k + 2 * lane + h;
+            const fe o = fold_one(a, i);
+            a.out[i] = o;
+            const digest d = leaf_digest(o.lo, o.hi);
+            a.leaf_out[i] = d;
+            if (h == 0) da = d;
+            else db = d;
+        }
+        const digest p = node_digest(da, db);
+        level1[first / 2 + 64 * k + lane] = p;
+        if (k == 0) pa = p;
+        else pb = p;
+    }
+    const int from = (int)((2 * lane) & 63);
+    digest l, r;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        const uint64_t la = __shfl(pa.w[w], from), lb = __shfl(pb.w[w], from);
+        const uint64_t ra = __shfl(pa.w[w], from + 1), rb = __shfl(pb.w[w], from + 1);
+        l.w[w] = lane < 32 ? la : lb;
+        r.w[w] = lane < 32 ? ra : rb;
+    }
+    level2[first / 4 + lane] = node_digest(l, r);
+}
+
 // Small layers: fold, leaf digests and the first nine tree levels in one launch
 // (a.leaf_out is level 0 of the new layer's tree, a.half its leaf count).
 __global__ __launch_bounds__(TAIL_THREADS) void fri_fold_tail_kernel(FoldArgs a, digest* root_out)
@@ -487,9 +528,11 @@ hipError_t launch_fri_fold_commit(const FoldArgs& a, hipStream_t s, digest* root
 {
     if (a.half == 0 || !a.leaf_out) return hipErrorInvalidValue;
     if (a.half > TAIL_MAX_CHILDREN) {
-        hipError_t e = launch_fri_fold(a, s);
+        if (a.half % 1024 || a.half / 1024 > 0x7fffffffull) return hipErrorInvalidValue;     // (a power of two above 2^17)
+        hipLaunchKernelGGL(fri_fold_subtree_kernel, dim3((uint32_t)(a.half / 1024)), dim3(256), 0, s, a);
+        hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
-        return launch_merkle_reduce(a.leaf_out, a.half, s, root_out);
+        return launch_merkle_reduce(a.leaf_out + a.half + a.half / 2, a.half / 4, s, root_out);
     }
     const size_t c_blk = a.half < TAIL_CHILDREN ? a.half : TAIL_CHILDREN;
     hipLaunchKernelGGL(fri_fold_tail_kernel, dim3((uint32_t)(a.half / c_blk)), dim3(TAIL_THREADS), 0, s, a, root_out);
