@@ -232,6 +232,37 @@ __global__ __launch_bounds__(256) void node_level_kernel(const digest* __restric
     out[i] = node_digest(l, r);
 }
 
+// Two levels per launch: a wave owns 256 consecutive digests of a level, as two blocks of 128; lane l hashes
+// the pair (2l, 2l+1) of each block, the 128 parents pair up across lanes as in leaf_subtree_kernel, and
+// every lane hashes one grandparent.  m_in is a multiple of 256; out1 / out2 are the next two levels.
+__global__ __launch_bounds__(256) void node_two_levels_kernel(const digest* __restrict__ in, digest* __restrict__ out1,
+                                                              digest* __restrict__ out2, size_t m_in)
+{
+    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t lane = threadIdx.x & 63;
+    if (wave * 256 >= m_in) return;                            // whole waves leave together
+    const size_t first = wave * 256;
+    digest pa{}, pb{};
+#pragma clang loop unroll(disable)
+    for (int k = 0; k < 2; k++) {
+        const size_t at = first + 128 * k + 2 * lane;
+        const digest p = node_digest(in[at], in[at + 1]);
+        out1[first / 2 + 64 * k + lane] = p;
+        if (k == 0) pa = p;
+        else pb = p;
+    }
+    const int from = (int)((2 * lane) & 63);
+    digest l, r;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        const uint64_t la = __shfl(pa.w[w], from), lb = __shfl(pb.w[w], from);
+        const uint64_t ra = __shfl(pa.w[w], from + 1), rb = __shfl(pb.w[w], from + 1);
+        l.w[w] = lane < 32 ? la : lb;
+        r.w[w] = lane < 32 ? ra : rb;
+    }
+    out2[first / 4 + lane] = node_digest(l, r);
+}
+
 // ---- four lanes per compression --------------------------------------------
 // Below about 2^17 nodes a level no longer fills the machine and its cost is
 // the latency of one compression.  There a compression is spread over the four
@@ -403,6 +434,14 @@ hipError_t launch_merkle_reduce(digest* level, size_t m, hipStream_t s, digest* 
                                 digest** roots_dev)
 {
     size_t m_tree = m / n_trees;
+    // two levels per launch while both are still wide (and a tree's share of the level is whole waves)
+    while (m_tree >= 256 && (m >> 1) > TAIL_MAX_CHILDREN && m % 1024 == 0 && m / 1024 <= 0x7fffffffull) {
+        hipLaunchKernelGGL(node_two_levels_kernel, dim3((uint32_t)(m / 1024)), dim3(256), 0, s, level, level + m,
+                           level + m + (m >> 1), m);
+        level += m + (m >> 1);
+        m >>= 2;
+        m_tree >>= 2;
+    }
     while (m_tree > 1 && m > TAIL_MAX_CHILDREN) {
         const size_t half = m >> 1;
         hipLaunchKernelGGL(node_level_kernel, dim3((uint32_t)((half + 255) / 256)), dim3(256), 0, s, level,
