@@ -195,6 +195,7 @@ struct ScaledStark {
     // on the trace length only) and the staging buffer of the randomizer's raw bytes
     mutable std::unique_ptr<DeviceVector> tz_coeffs;
     mutable std::vector<uint8_t> random_staging;
+    mutable std::vector<FieldElement> column_staging;         // the trace by columns, on its way to the device
 
     // stark.rs:34-86 without the assertion on omicron's value (:65) and without the table of
     // omicron's powers (:63), which only the zeroifier needed
@@ -369,11 +370,14 @@ struct ScaledStark {
         ProofStream ps;
 
         // ---- trace columns with their randomizers (:237-253), interpolated (:260-275)
-        std::vector<FieldElement> columns(R * n_rows);
+        // (the staging vector is kept from proof to proof: a fresh one costs a page fault per 4 KiB written and
+        // a slower first transfer, together more than the copy itself at 2^20 rows)
+        if (column_staging.size() != R * n_rows) column_staging.assign(R * n_rows, FieldElement::zero());
+        std::vector<FieldElement>& columns = column_staging;
         {
             // rows to columns: every row is a heap object of its own, so this is a walk through memory;
             // a few threads take a range of cycles each
-            const size_t workers = T >= ((size_t)1 << 16) ? 4 : 1;
+            const size_t workers = T >= ((size_t)1 << 16) ? 8 : 1;
             std::vector<std::thread> pool;
             std::vector<int> bad(workers, 0);
             for (size_t w = 0; w < workers; w++)
@@ -399,14 +403,16 @@ struct ScaledStark {
                     columns[s * n_rows + T + k] = FieldElement::sample(std::vector<uint8_t>(b, b + 17));
                 }
         }
+        DeviceVector trace_values(R * n_rows), tp(R * n_rows);
+        trace_values.upload(columns);
         // the randomizer polynomial's raw bytes (:344-353) are the next thing the random source yields: they are
-        // drawn on a helper thread while the device works on the trace (tens of megabytes for a long trace)
+        // drawn on a helper thread while the device works on the trace (tens of megabytes for a long trace).  The
+        // draw starts after the trace has gone up: side by side the two copies fight for the memory system and
+        // the upload takes 7 ms instead of 1.
         const size_t max_deg = max_degree(air);
         const size_t n_random = 17 * (max_deg + 1);
         if (random_staging.size() < n_random) random_staging.resize(n_random);
         std::future<void> drawn = std::async(std::launch::async, [&] { rng(random_staging.data(), n_random); });
-        DeviceVector trace_values(R * n_rows), tp(R * n_rows);
-        trace_values.upload(columns);
         lap(tm.host);
         geo.interpolate(trace_values.words(), n_rows, R, n_rows, tp.words(), n_rows);
         std::unique_ptr<DeviceVector> constants = constant_polynomials(constant_columns);
