@@ -424,9 +424,11 @@ struct ChainJob {
     ScaledStark stark;
     std::vector<std::vector<FieldElement>> trace, constants;
     std::vector<MPolynomial> air;
+    std::unique_ptr<DeviceVector> constant_polys;    // the statement's public polynomials, made once
+    bool use_prepared = true;                        // off: prove and verify interpolate the constant columns themselves
     ChainJob(const FieldElement& input, size_t rows, size_t expansion, size_t ncol, size_t security)
         : chain(rows), stark(expansion, ncol, security, chain.rp.m, rows), trace(chain.trace(input)),
-          constants(chain.constant_columns()), air(chain.air())
+          constants(chain.constant_columns()), air(chain.air()), constant_polys(stark.constant_polynomials(constants))
     {
     }
 };
@@ -457,6 +459,7 @@ void sh_chain_corrupt(void* h, size_t row, size_t reg)
     ChainJob* j = (ChainJob*)h;
     j->trace.at(row).at(reg) = j->trace[row][reg] + FieldElement::one();
 }
+void sh_chain_use_prepared_constants(void* h, int on) { ((ChainJob*)h)->use_prepared = on != 0; }
 size_t sh_chain_fri_domain_length(void* h) { return ((ChainJob*)h)->stark.fri_domain_length; }
 // returns the random bytes used; timings (may be NULL) receives host, interpolate, quotients, lde, merkle, fri,
 // openings, total in milliseconds
@@ -473,7 +476,8 @@ int sh_chain_prove(void* h, const uint8_t* random, size_t n_random, uint8_t* pro
         };
         ProveTimings tm;
         std::vector<uint8_t> proof = j->stark.prove(j->trace, j->air, j->constants,
-                                                    j->chain.boundary_constraints(j->trace.back()[0]), rng, &tm);
+                                                    j->chain.boundary_constraints(j->trace.back()[0]), rng, &tm,
+                                                    j->use_prepared ? j->constant_polys.get() : nullptr);
         if (proof_out) {
             if (*proof_len < proof.size()) throw Panic("proof buffer too small");
             std::memcpy(proof_out, proof.data(), proof.size());
@@ -491,7 +495,8 @@ int sh_chain_verify(void* h, const uint64_t* output, const uint8_t* proof, size_
     GUARD(
         ChainJob* j = (ChainJob*)h;
         return j->stark.verify(std::vector<uint8_t>(proof, proof + proof_len), j->air, j->constants,
-                               j->chain.boundary_constraints(ld(output)))
+                               j->chain.boundary_constraints(ld(output)),
+                               j->use_prepared ? j->constant_polys.get() : nullptr)
                    ? 1
                    : 0;)
 }

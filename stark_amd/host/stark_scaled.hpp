@@ -344,10 +344,13 @@ struct ScaledStark {
     // the transition from cycle c to c + 1; the AIR's variables are [x, registers at c, registers at c + 1,
     // constants].  `rng` is read as ONE byte stream in the reference's drawing order: 17 bytes per randomizer
     // value row by row (:237-253), then 17 bytes per randomizer coefficient, highest degree first (:344-353).
+    // `prepared`, if given, is constant_polynomials(constant_columns) made beforehand: the columns are public
+    // parameters of the statement (the reference receives the round-constant polynomials inside its
+    // transition constraints, made by rescue_prime.rs:309-359 before Stark::prove is called).
     std::vector<uint8_t> prove(const std::vector<std::vector<FieldElement>>& trace, const std::vector<MPolynomial>& air,
                                const std::vector<std::vector<FieldElement>>& constant_columns,
                                const std::vector<BoundaryCondition>& boundary, const RandomSource& rng,
-                               ProveTimings* timings = nullptr) const
+                               ProveTimings* timings = nullptr, const DeviceVector* prepared = nullptr) const
     {
         typedef std::chrono::steady_clock Clock;
         stark_ctx* ctx = context();
@@ -415,7 +418,11 @@ struct ScaledStark {
         std::future<void> drawn = std::async(std::launch::async, [&] { rng(random_staging.data(), n_random); });
         lap(tm.host);
         geo.interpolate(trace_values.words(), n_rows, R, n_rows, tp.words(), n_rows);
-        std::unique_ptr<DeviceVector> constants = constant_polynomials(constant_columns);
+        std::unique_ptr<DeviceVector> made;
+        if (!prepared) made = constant_polynomials(constant_columns);
+        const DeviceVector* constants = prepared ? prepared : made.get();
+        if (constants->count < std::max<size_t>(1, constant_columns.size() * (T - 1)))
+            throw Panic("prepared constant polynomials do not match the constant columns");
         lap(tm.interpolate);
 
         // ---- boundary quotients (:277-288): (trace polynomial - interpolant) / zeroifier on a coset
@@ -618,7 +625,7 @@ struct ScaledStark {
     // Stark::verify (:474-723) with the constant columns' polynomials evaluated at the opened points
     bool verify(const std::vector<uint8_t>& proof, const std::vector<MPolynomial>& air,
                 const std::vector<std::vector<FieldElement>>& constant_columns,
-                const std::vector<BoundaryCondition>& boundary) const
+                const std::vector<BoundaryCondition>& boundary, const DeviceVector* prepared = nullptr) const
     {
         size_t max_cycle = 0;
         for (const auto& b : boundary) max_cycle = std::max(max_cycle, std::get<0>(b));
@@ -681,7 +688,10 @@ struct ScaledStark {
         std::vector<FieldElement> constant_values(indices.size() * K), tz_values(indices.size());
         if (K && !indices.empty()) {
             if (indices.size() > 16) throw Panic("more opened points than one evaluation call takes");
-            std::unique_ptr<DeviceVector> polys = constant_polynomials(constant_columns);
+            std::unique_ptr<DeviceVector> made;
+            if (!prepared) made = constant_polynomials(constant_columns);
+            const DeviceVector* polys = prepared ? prepared : made.get();
+            if (polys->count < K * steps) throw Panic("prepared constant polynomials do not match the constant columns");
             std::vector<uint64_t> pts(2 * xs.size()), vals(2 * K * xs.size());
             for (size_t i = 0; i < xs.size(); i++) fe_words(xs[i], &pts[2 * i]);
             check(stark_poly_eval_points_dev(context(), polys->words(), steps, K, steps, pts.data(), xs.size(), vals.data()));

@@ -434,3 +434,20 @@ def test_repeated_proofs_do_not_grow_device_memory(hm):
         assert free_before - torch.cuda.mem_get_info()[0] < (64 << 20)
     finally:
         job.free()
+
+
+def test_prepared_and_unprepared_constant_polynomials_agree(hm):
+    """The constant columns' polynomials made once with the statement, or interpolated inside every prove
+    and verify call: the same proof bytes and the same verdicts."""
+    job = _Chain(hm, 4242, 1 << 11)
+    try:
+        random = hashlib.shake_256(b"prepared").digest(job.random_bytes)
+        proof, _ = job.prove(random)
+        assert job.verify(job.output, proof) == 1
+        hm.lib.sh_chain_use_prepared_constants(job.h, 0)
+        again, _ = job.prove(random)
+        assert again == proof
+        assert job.verify(job.output, proof) == 1
+        assert job.verify((job.output + 1) % P, proof) == 0
+    finally:
+        job.free()
