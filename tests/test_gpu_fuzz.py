@@ -1,6 +1,7 @@
 """Seeded random sweeps of the device entry points against the CPU restatement: shapes nobody wrote a
 case for (odd column counts and strides, partly filled columns, every transform length up to 2^15 in
 both directions, in place and out of place).  Bit-exact like every other parity test."""
+import os
 import random
 
 import numpy as np
@@ -12,6 +13,7 @@ import oracle_c as oc          # noqa: E402
 import stark_oracle as so      # noqa: E402
 
 P, G = so.P, so.GENERATOR
+SEED = int(os.environ.get("STARK_FUZZ_SEED", "0"))       # another sweep: STARK_FUZZ_SEED=1 pytest tests/test_gpu_fuzz.py
 
 
 @pytest.fixture(scope="module")
@@ -36,14 +38,14 @@ def _host(t, shape):
 def test_random_batched_transforms(ctx):
     """stark_ntt_batch_dev: random length 2^0 .. 2^15, column count, stride and direction; the gaps between
     the columns must come back untouched and the inverse must give the input back."""
-    rng = random.Random(20261111)
+    rng = random.Random(20261111 + SEED)
     for case in range(140):
         log_n = rng.randrange(0, 16)
         n = 1 << log_n
         cols = rng.choice([1, 2, 3, 5, 8, 17, 33, 100, 257]) if log_n <= 10 else rng.choice([1, 2, 3, 7])
         stride = n + rng.choice([0, 0, 1, 3, 16])
         inverse = bool(rng.getrandbits(1))
-        x = oc.splitmix(stride * cols, 9000 + case).reshape(cols, stride, 2)
+        x = oc.splitmix(stride * cols, 9000 + case + 100000 * SEED).reshape(cols, stride, 2)
         if case % 9 == 0:                                  # structured columns: zeros, ones, p - 1
             x[0, :n] = 0
             x[-1, :n] = oc.fe(P - 1)
@@ -62,7 +64,7 @@ def test_random_batched_transforms(ctx):
 def test_random_coset_extensions(ctx):
     """stark_coset_lde_batch_dev: random coefficient count (not a power of two, down to one), output
     length, column count, strides and offset, against Polynomial::eval_domain on offset * omega^i."""
-    rng = random.Random(77)
+    rng = random.Random(77 + SEED)
     for case in range(70):
         log_out = rng.randrange(0, 15)
         n_out = 1 << log_out
@@ -71,7 +73,7 @@ def test_random_coset_extensions(ctx):
         c_stride = n_coeffs + rng.choice([0, 0, 2, 5])
         o_stride = n_out + rng.choice([0, 0, 1, 8])
         offset = rng.choice([1, G, 2, P - 1, rng.randrange(1, P)])
-        coeffs = oc.splitmix(c_stride * cols, 400 + case).reshape(cols, c_stride, 2)
+        coeffs = oc.splitmix(c_stride * cols, 400 + case + 100000 * SEED).reshape(cols, c_stride, 2)
         out = oc.splitmix(o_stride * cols, 800 + case).reshape(cols, o_stride, 2)
         d_c, d_o = _dev(coeffs), _dev(out)
         ctx.coset_lde_batch_dev(d_c, n_coeffs, c_stride, cols, n_out, offset, d_o, o_stride)
@@ -86,11 +88,11 @@ def test_random_coset_extensions(ctx):
 def test_random_trees_and_folds(ctx):
     """Merkle::commit over field elements and one FRI fold at random lengths; root, every opened path and
     the folded codeword against the restatement."""
-    rng = random.Random(5)
+    rng = random.Random(5 + SEED)
     for case in range(40):
         log_n = rng.randrange(0, 15)
         n = 1 << log_n
-        x = oc.splitmix(n, 1200 + case)
+        x = oc.splitmix(n, 1200 + case + 100000 * SEED)
         if case % 5 == 0:
             x[rng.randrange(n)] = oc.fe(rng.choice([0, 1, 255, 256, (1 << 32) - 1, 1 << 32, 1 << 64, (1 << 96) - 1, P - 1]))
         root, tree = ctx.merkle_commit_fe(x, keep_tree=True)
