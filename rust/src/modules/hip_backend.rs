@@ -1,6 +1,6 @@
 //! New bodies of the reference's hot-path functions over the C ABI (hip_ffi.rs).  New file of the patched
 //! `zk_stark` crate: `src/modules/hip_backend.rs`.  The reference's methods keep their signatures and
-//! delegate here with one line each (the list is in INTEGRATION.md §3); nothing else in the reference
+//! delegate here with one line each (every function below names the method it is the body of); nothing else in the reference
 //! changes.  Not compiled where it was written (no Rust toolchain there): tests/golden_parity.rs is the
 //! first thing to run on a machine that has cargo.
 #![allow(dead_code)]
