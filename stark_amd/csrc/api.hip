@@ -57,6 +57,7 @@ struct NttTables {
     bool plane_refused = false;      // the allocation failed once: do not try again
     fe* small = nullptr;             // omega_n^i, i < n/2 (n <= 4096), Montgomery form (2^128)
     fe scale_m{0, 0};                // n^-1, Montgomery form (2^128)
+    tw5 scale5{};                    // n^-1, five-limb Montgomery form (2^156)
 };
 
 // powers of one element x: lo[i] = x^i (i<256), hi[i] = x^(256 i); either as
@@ -350,26 +351,26 @@ static int32_t get_ntt_tables(stark_ctx* ctx, uint32_t log_n, bool inverse, cons
     if (inverse) omega = F.inverse(omega);                    // ntt.rs:19
     fe n_inv = F.inverse(fe{(u64)1 << log_n, 0});             // ntt.rs:36
     t.scale_m = F.to_mont(n_inv);
+    t.scale5 = to_tw5(F, n_inv);
     int32_t rc = STARK_OK;
-    if (log_n <= 8) {                                         // the single-workgroup kernel: n < 32, coset and padded transforms
+    // the lazy-limb kernels carry the powers of the 16th root as literals (tw16_tables.hpp); they must be
+    // the powers of THIS field's root (omega^(n/16) where n allows)
+    {
+        fe w16 = F.primitive_nth_root(4);
+        if (inverse) w16 = F.inverse(w16);
+        if (!tw16_literals_match(F, w16, inverse))
+            return fail(STARK_EARG, "the compiled-in 16th-root table does not match primitive_nth_root");
+    }
+    if (log_n <= 8) {                                         // the single-workgroup kernel: coset and padded transforms
         size_t half = log_n ? ((size_t)1 << (log_n - 1)) : 1;
         rc = upload(ctx, powers_m(F, omega, half), &t.small);
     }
     if (rc == STARK_OK && log_n >= (uint32_t)SHORT_MIN_LOG) {
         t.radices = plan_radices(log_n);
         t.h = t.radices.back();
-        fe w16 = F.primitive_nth_root(4), w256 = F.primitive_nth_root(8);   // omega^(n/16), omega^(n/256) where n allows
-        if (inverse) {
-            w16 = F.inverse(w16);
-            w256 = F.inverse(w256);
-        }
+        fe w256 = F.primitive_nth_root(8);                    // omega^(n/256) where n allows
+        if (inverse) w256 = F.inverse(w256);
         fe w_hi = F.pow(omega, (u128)1 << t.h);
-        // the kernels carry the powers of the 16th root as literals (tw16_tables.hpp); they must be the
-        // powers of THIS root
-        if (!tw16_literals_match(F, w16, inverse)) {
-            free_ntt_tables(t);
-            return fail(STARK_EARG, "the compiled-in 16th-root table does not match primitive_nth_root");
-        }
         // a one-pass inverse has no outgoing twiddle to carry n^-1 (ntt.rs:36-39): it rides on the exchange
         // twiddles instead, which every element meets exactly once
         const bool one_pass = t.radices.size() == 1;
@@ -447,10 +448,22 @@ static int32_t run_ntt(stark_ctx* ctx, const fe* src, size_t src_stride, size_t 
     ST_TRY(get_ntt_tables(ctx, log_n, inverse, &t));
     const size_t n = (size_t)1 << log_n;
     // the tiled passes take everything from 512 points up, and plain transforms (no coset shift, no zero
-    // padding) from 32 points; the rest runs in one workgroup
+    // padding) from 32 points; plain transforms of up to 16 points run one per thread; the rest (coset
+    // and padded transforms below 512 points) runs in one workgroup each
     const bool tiled = log_n >= 9 || (log_n >= (uint32_t)SHORT_MIN_LOG && !twist_x && n_src == n);
     PowRef twist;
     if (twist_x) ST_TRY(get_pow_tables(ctx, *twist_x, n_src, tiled, &twist));
+    if (log_n <= (uint32_t)TINY_MAX_LOG && !twist_x && n_src == n) {       // one thread per transform
+        TinyArgs a{};
+        a.src = src;
+        a.dst = dst;
+        a.src_batch_stride = src_stride;
+        a.dst_batch_stride = dst_stride;
+        a.n_batch = n_cols;
+        a.scale5 = t->scale5;
+        HIP_TRY(launch_ntt_tiny(a, log_n, inverse, ctx->stream));
+        return STARK_OK;
+    }
     if (!tiled) {
         SmallArgs a{};
         a.tw = t->small;

@@ -17,7 +17,7 @@ using starkh::digest;
 
 constexpr int TILE_ELEMS = 4096;      // elements per workgroup tile
 constexpr int TILE_THREADS = 256;
-constexpr int SMALL_MAX_LOG = 8;      // the single-workgroup kernel (ntt_small_kernel) serves n < 32 and coset or padded n <= 256
+constexpr int SMALL_MAX_LOG = 8;      // the single-workgroup kernel (ntt_small_kernel) serves coset or padded n <= 256
 constexpr int SHORT_MIN_LOG = 5;      // 32 .. 256 points: one pass (a tile spans 4096 / n transforms); 512: radix 16 then 32
 constexpr int MAX_PASSES = 4;
 
@@ -69,6 +69,17 @@ struct SmallArgs {
     uint32_t has_scale, has_twist;
 };
 hipError_t launch_ntt_small(const SmallArgs& a, uint32_t n_batch, hipStream_t s);
+
+// Plain transforms of at most 16 points, one thread each.
+struct TinyArgs {
+    const fe* src;
+    fe* dst;
+    uint64_t src_batch_stride, dst_batch_stride;
+    uint64_t n_batch;
+    tw5 scale5;            // n^-1 as a five-limb Montgomery form (inverse only)
+};
+constexpr int TINY_MAX_LOG = 4;
+hipError_t launch_ntt_tiny(const TinyArgs& a, uint32_t log_n, bool inverse, hipStream_t s);
 
 // data[i][k] *= w^((row_start + i) * k) for an n_rows x n_cols row-major block;
 // hi/lo are the 16-byte power tables of w (lo[e] = w^e, e<256; hi[e] = w^(256 e)).

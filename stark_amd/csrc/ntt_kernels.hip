@@ -594,8 +594,8 @@ hipError_t launch_ntt_pass(const PassArgs& a_in, PassMode mode, bool twist, uint
 }
 
 // ---------------------------------------------------------------------------
-// n < 32, and coset or zero-padded transforms of fewer than 512 points: the whole transform lives in
-// one workgroup's LDS.
+// Coset or zero-padded transforms of fewer than 512 points: the whole transform lives in one
+// workgroup's LDS.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(TILE_THREADS) void ntt_small_kernel(SmallArgs a)
 {
@@ -639,6 +639,58 @@ hipError_t launch_ntt_small(const SmallArgs& a, uint32_t n_batch, hipStream_t s)
     if (a.log_n > (uint32_t)SMALL_MAX_LOG) return hipErrorInvalidValue;
     hipLaunchKernelGGL(ntt_small_kernel, dim3(n_batch), dim3(TILE_THREADS), 0, s, a);
     return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// Plain transforms of at most 16 points: one THREAD per transform, the whole of it in registers on the
+// lazy-limb core (the butterfly network of the pass kernels' second round, cut to the length).  The
+// inverse's n^-1 (ntt.rs:36-39) is one product per output, which also brings the limbs back to a
+// canonical value; the forward outputs are reduced without a product.
+// ---------------------------------------------------------------------------
+template <int LOGN, bool INV>
+__global__ __launch_bounds__(TILE_THREADS) void ntt_tiny_kernel(TinyArgs a)
+{
+    constexpr int N = 1 << LOGN;
+    const uint64_t b = (uint64_t)blockIdx.x * TILE_THREADS + threadIdx.x;
+    if (b >= a.n_batch) return;
+    const fe* __restrict__ src = a.src + b * a.src_batch_stride;
+    fe* __restrict__ dst = a.dst + b * a.dst_batch_stride;
+    fe raw[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) raw[i] = src[i];
+    fe5 v[16];
+#pragma unroll
+    for (int i = 0; i < N; i++) v[i] = unpack5(raw[i]);
+    ntt_dif_reg<LOGN, 0, INV>(v);
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        const fe5 x = v[brev_c(k, LOGN)];
+        if constexpr (INV) dst[k] = pack_canonical(mont_mul5_s(x, a.scale5));
+        else dst[k] = finish_lazy(x);
+    }
+}
+
+template <int LOGN>
+static hipError_t launch_tiny_n(const TinyArgs& a, bool inverse, hipStream_t s)
+{
+    const uint64_t blocks = (a.n_batch + TILE_THREADS - 1) / TILE_THREADS;
+    if (blocks == 0) return hipSuccess;
+    if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
+    if (inverse) hipLaunchKernelGGL((ntt_tiny_kernel<LOGN, true>), dim3((uint32_t)blocks), dim3(TILE_THREADS), 0, s, a);
+    else hipLaunchKernelGGL((ntt_tiny_kernel<LOGN, false>), dim3((uint32_t)blocks), dim3(TILE_THREADS), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_ntt_tiny(const TinyArgs& a, uint32_t log_n, bool inverse, hipStream_t s)
+{
+    switch (log_n) {
+    case 0: return launch_tiny_n<0>(a, inverse, s);
+    case 1: return launch_tiny_n<1>(a, inverse, s);
+    case 2: return launch_tiny_n<2>(a, inverse, s);
+    case 3: return launch_tiny_n<3>(a, inverse, s);
+    case 4: return launch_tiny_n<4>(a, inverse, s);
+    }
+    return hipErrorInvalidValue;
 }
 
 // Pointwise canonical product (ntt.rs:125-127).  r2 = 2^256 mod p.
