@@ -80,9 +80,13 @@ def test_ntt_batch(ctx):
     # 2^5 .. 2^8: one pass, 128 .. 16 transforms to a tile; 2^9: a radix-16 pass without exchange, then radix 32
     for log_n, cols in ((5, 7), (13, 5), (16, 3), (10, 1), (10, 7), (10, 8), (11, 3), (11, 130),
                         (5, 1), (5, 128), (5, 129), (6, 65), (7, 1), (7, 33), (8, 16), (8, 17), (8, 1000),
-                        (9, 1), (9, 8), (9, 9), (9, 300), (4, 5), (3, 300)):
+                        (9, 1), (9, 8), (9, 9), (9, 300), (4, 5), (3, 300),
+                        # up to 16 points: one transform per thread, the last workgroup partly filled
+                        (0, 5), (1, 300), (2, 257), (4, 256), (4, 1000)):
         n = 1 << log_n
         x = oc.splitmix(n * cols, 77 + log_n).reshape(cols, n, 2)
+        x[0] = 0                                               # a zero column, and one of p - 1 throughout
+        x[-1] = oc.fe(so.P - 1)
         out = ctx.ntt_batch(x)
         for c in range(cols):
             assert np.array_equal(out[c], oc.ntt(x[c]))
@@ -90,7 +94,7 @@ def test_ntt_batch(ctx):
         assert np.array_equal(back, x)
 
 
-@pytest.mark.parametrize("log_n,cols", [(5, 40), (8, 19), (9, 11), (10, 5)])
+@pytest.mark.parametrize("log_n,cols", [(2, 300), (4, 70), (5, 40), (8, 19), (9, 11), (10, 5)])
 def test_ntt_batch_strided_columns_in_place(ctx, log_n, cols):
     """Short transforms sharing a tile, columns further apart than their length, transformed in place on the
     device: the gaps between the columns must come back untouched."""
