@@ -312,7 +312,7 @@ static bool tw16_literals_match(const HostField& F, fe w16, bool inverse)
     return true;
 }
 
-// Sizes up to this keep a twiddle plane (20 bytes per element and direction: 1.3 GB at 2^26).
+// Sizes up to this keep a twiddle plane (20 bytes per element, shared by both directions: 1.3 GB at 2^26).
 constexpr uint32_t PLANE_MAX_LOG = 26;
 
 static std::vector<uint32_t> plan_radices(uint32_t log_n)
@@ -366,20 +366,19 @@ static int32_t get_ntt_tables(stark_ctx* ctx, uint32_t log_n, bool inverse, cons
         rc = upload(ctx, powers_m(F, omega, half), &t.small);
     }
     if (rc == STARK_OK && log_n >= (uint32_t)SHORT_MIN_LOG) {
+        // The tiled passes run an inverse transform as the forward one with its outputs stored in reversed
+        // order (sum_j x[j] w^(-jk) is the forward sum at index -k), so both directions share the forward
+        // root's hi/lo tables and twiddle plane; the inverse's entry only holds the exchange twiddles of its
+        // last pass, scaled by n^-1 (ntt.rs:36-39: every element meets exactly one of them).
         t.radices = plan_radices(log_n);
         t.h = t.radices.back();
-        fe w256 = F.primitive_nth_root(8);                    // omega^(n/256) where n allows
-        if (inverse) w256 = F.inverse(w256);
-        fe w_hi = F.pow(omega, (u128)1 << t.h);
-        // a one-pass inverse has no outgoing twiddle to carry n^-1 (ntt.rs:36-39): it rides on the exchange
-        // twiddles instead, which every element meets exactly once
-        const bool one_pass = t.radices.size() == 1;
-        rc = upload(ctx, powers_5(F, w256, 256, (inverse && one_pass) ? n_inv : fe{1, 0}), &t.tw256);
-        if (rc == STARK_OK) rc = upload(ctx, powers_5(F, w_hi, (size_t)1 << (log_n - t.h)), &t.hi);
-        // ntt.rs:36-39: the inverse's n^-1 rides on the lo table, which enters exactly one product per
-        // element (the outgoing twiddle of the pass before the last); the last pass multiplies nothing
-        if (rc == STARK_OK)
-            rc = upload(ctx, powers_5(F, omega, (size_t)1 << t.h, (inverse && !one_pass) ? n_inv : fe{1, 0}), &t.lo);
+        const fe w256 = F.primitive_nth_root(8);              // omega^(n/256) where n allows
+        rc = upload(ctx, powers_5(F, w256, 256, inverse ? n_inv : fe{1, 0}), &t.tw256);
+        if (!inverse) {
+            const fe w_hi = F.pow(omega, (u128)1 << t.h);
+            if (rc == STARK_OK) rc = upload(ctx, powers_5(F, w_hi, (size_t)1 << (log_n - t.h)), &t.hi);
+            if (rc == STARK_OK) rc = upload(ctx, powers_5(F, omega, (size_t)1 << t.h), &t.lo);
+        }
     }
     if (rc != STARK_OK) {
         free_ntt_tables(t);                                   // nothing half-built stays behind
@@ -446,6 +445,8 @@ static int32_t run_ntt(stark_ctx* ctx, const fe* src, size_t src_stride, size_t 
     if (n_cols == 0) return STARK_OK;
     const NttTables* t;
     ST_TRY(get_ntt_tables(ctx, log_n, inverse, &t));
+    const NttTables* tf = t;                                  // the forward root's tables (shared by the tiled passes)
+    if (inverse && log_n >= (uint32_t)SHORT_MIN_LOG) ST_TRY(get_ntt_tables(ctx, log_n, false, &tf));
     const size_t n = (size_t)1 << log_n;
     // the tiled passes take everything from 512 points up, and plain transforms (no coset shift, no zero
     // padding) from 32 points; plain transforms of up to 16 points run one per thread; the rest (coset
@@ -498,9 +499,9 @@ static int32_t run_ntt(stark_ctx* ctx, const fe* src, size_t src_stride, size_t 
             log_s -= t->radices[q];
             PassArgs a{};
             a.inverse = inverse ? 1 : 0;
-            a.tw256 = t->tw256;
-            a.hi = t->hi;
-            a.lo = t->lo;
+            a.tw256 = (q == P - 1) ? t->tw256 : tf->tw256;    // the inverse's n^-1 rides on its last pass's exchange
+            a.hi = tf->hi;
+            a.lo = tf->lo;
             a.log_n = log_n;
             a.log_s = log_s;
             a.log_s_next = (q + 1 < P) ? log_s - t->radices[q + 1] : 0;
@@ -532,8 +533,8 @@ static int32_t run_ntt(stark_ctx* ctx, const fe* src, size_t src_stride, size_t 
                 a.dst_batch_stride = n;
             }
             if (a.next_is_last && log_n <= PLANE_MAX_LOG) {
-                // the twiddle plane of this pass: 20 bytes per element, built once per size and direction
-                NttTables* tm = const_cast<NttTables*>(t);
+                // the twiddle plane of this pass: 20 bytes per element, built once per size
+                NttTables* tm = const_cast<NttTables*>(tf);
                 if (!tm->plane && !tm->plane_refused) {
                     if (hipMalloc((void**)&tm->plane, (size_t)20 << log_n) != hipSuccess) {
                         (void)hipGetLastError();          // no room: this size keeps forming hi*lo per element

@@ -26,9 +26,9 @@ constexpr int MAX_PASSES = 4;
 struct PassArgs {
     const fe* src;
     fe* dst;
-    const tw5* tw256;      // omega_256^i, i<256
+    const tw5* tw256;      // omega_256^i, i<256 (times n^-1 in the last pass of an inverse transform)
     const tw5* hi;         // omega_n^(i << h), i < n >> h
-    const tw5* lo;         // omega_n^i, i < 2^h (times n^-1 for the inverse transform)
+    const tw5* lo;         // omega_n^i, i < 2^h
     const tw5* twist_hi;   // s^(256 i), first pass of a coset transform
     const tw5* twist_lo;   // s^i, i<256
     uint64_t src_batch_stride;   // elements between consecutive transforms of a batch
@@ -43,7 +43,7 @@ struct PassArgs {
     uint32_t nprev;        // q
     uint32_t rprev[MAX_PASSES];   // log2 R_u, u < q
     uint32_t n_batch;             // transforms in the launch (set by launch_ntt_pass)
-    uint32_t inverse;             // 1: the butterfly constants are those of the inverse root (ntt.rs:19)
+    uint32_t inverse;             // 1: inverse transform (ntt.rs:19): the last pass stores output k at (n - k) mod n
     // Pass before the last only: its outgoing twiddle omega_n^(j_next * K) has all of n as exponent
     // range.  If set, plane[5 i .. 5 i + 4] holds the five limbs of the twiddle of output element i
     // (same index as dst); otherwise the kernel multiplies hi and lo entries together per element.

@@ -162,10 +162,21 @@ __device__ __forceinline__ void locate(const PassArgs& a, uint64_t tile, int c, 
     }
 }
 
+// Last pass of an inverse transform: output k of the forward sums goes to index (n - k) mod n.  A tile's
+// rows are whole columns b of the n / R it could own in any order, so it takes the columns one further
+// on, b + 1 ... b + C (mod n / R): the C outputs of one k then land on an ALIGNED run of C elements,
+// n - (k n/R + b) - C ... - 1, instead of one that straddles two (a 6 % slower pass at 2^24).
+template <bool INV>
+__device__ __forceinline__ uint64_t last_pass_column(const PassArgs& a, uint64_t b)
+{
+    if constexpr (INV) return (b + 1) & (((uint64_t)1 << (a.log_n - a.r)) - 1);
+    else return b;
+}
+
 // Issue the 16 global loads of one thread for one tile (round-1 layout).
 // tile enumerates (batch, tile-in-transform); rows past n_src of a first pass
 // are the zero padding and are not read.
-template <int RA, int MODE, bool SMALL>
+template <int RA, int MODE, bool SMALL, bool INV>
 __device__ __forceinline__ void load_tile(fe (&raw)[16], const PassArgs& a, uint64_t tile, int t)
 {
     constexpr int M1 = 1 << RA;
@@ -179,6 +190,7 @@ __device__ __forceinline__ void load_tile(fe (&raw)[16], const PassArgs& a, uint
             const int c = q1 >> 4, jb = q1 & 15;
             uint64_t batch, b;                                     // b: low part of the output index
             locate<RA, SMALL>(a, tile, c, batch, b);
+            b = last_pass_column<INV>(a, b);
             const fe* __restrict__ src = a.src + batch * a.src_batch_stride;
             const uint64_t row = (uint64_t)k_to_prefix((uint32_t)b, a) << a.r;
 #pragma unroll
@@ -289,11 +301,11 @@ __device__ __forceinline__ void unpack_tile(fe5 (&v)[16], const fe (&raw)[16], c
 // A thread's 16 inputs all have ka = t >> LOGC, so waves 0-1 collect theirs in
 // phase 0 and waves 2-3 in phase 1.  Ends with every thread's LDS reads issued
 // and waited for, but NOT with a barrier.
-template <int RA, int MODE, bool INV>
+template <int RA, int MODE>
 __device__ __forceinline__ void round1_exchange(fe5 (&v)[16], fe5* lds, const tw5* s_tw256, int t)
 {
     using G = Geo<RA, MODE>;
-    RoundOne<RA, G::G1, INV>::run(v);
+    RoundOne<RA, G::G1, false>::run(v);
     const int ka2 = t >> G::LOGC, c2 = t & (G::C - 1);
     const int my_phase = ka2 / G::KA_HALF;
     fe5 rcv[16];
@@ -328,6 +340,9 @@ __device__ __forceinline__ void round1_exchange(fe5 (&v)[16], fe5* lds, const tw
 // round 2 (radix 16 over jb), outgoing twiddle, store
 // NEXT_LAST: 0 = the next pass is not the last, 1 = it is and the twiddle is formed as hi*lo, 2 = it is
 // and the twiddle comes from the plane
+// INV (last pass only): the transform is an inverse one.  It runs as the forward transform with the
+// forward root's tables, and output k is stored at index (n - k) mod n: sum_j x[j] w^(-jk) is the forward
+// sum at -k (ntt.rs:19,30-39; the factor n^-1 rides on the exchange twiddles of this pass).
 template <int RA, int MODE, int NEXT_LAST, bool SMALL, bool INV>
 __device__ __forceinline__ void round2_store(fe5 (&v)[16], const PassArgs& a, uint64_t tile, int t)
 {
@@ -344,15 +359,17 @@ __device__ __forceinline__ void round2_store(fe5 (&v)[16], const PassArgs& a, ui
     bool live = true;                                      // a shared tile may reach past the end of the batch
     if constexpr (SMALL) live = batch < a.n_batch;
     if constexpr (MODE == PASS_LAST) {
-        ntt_dif_reg<4, 0, INV>(v);
-        const uint64_t b = f;
+        ntt_dif_reg<4, 0, false>(v);
+        const uint64_t b = last_pass_column<INV>(a, f);
         const uint32_t sh = a.log_n - a.r;
 #pragma unroll
         for (int kb = 0; kb < 16; kb++) {
             uint32_t k = ka2 + M1 * kb;
             asm volatile("" : "+v"(k));
             const fe o = finish_lazy(v[brev_c(kb, 4)]);
-            if (live) dst[((uint64_t)k << sh) + b] = o;
+            uint64_t idx = ((uint64_t)k << sh) + b;
+            if constexpr (INV) idx = (0 - idx) & (((uint64_t)1 << a.log_n) - 1);
+            if (live) dst[idx] = o;
         }
     } else {
         const uint32_t pre = (uint32_t)(f >> a.log_s);
@@ -380,7 +397,7 @@ __device__ __forceinline__ void round2_store(fe5 (&v)[16], const PassArgs& a, ui
                     asm volatile("" : "+v"(k));
                     w[kb & 1] = *(const fe5*)(plane + 5 * (base + ((uint64_t)k << a.log_s)));
                 };
-                ntt_dif_reg<4, 0, INV>(v);
+                ntt_dif_reg<4, 0, false>(v);
                 issue(0);
 #pragma clang loop unroll(full)
                 for (int kb = 0; kb < 16; kb++) {
@@ -405,7 +422,7 @@ __device__ __forceinline__ void round2_store(fe5 (&v)[16], const PassArgs& a, ui
                 }
             };
             // (two tables: the first batch waits until the butterflies have released their registers)
-            ntt_dif_reg<4, 0, INV>(v);
+            ntt_dif_reg<4, 0, false>(v);
             issue(0);
 #pragma clang loop unroll(full)
             for (int bt = 0; bt < 16 / B; bt++) {
@@ -433,7 +450,7 @@ __device__ __forceinline__ void round2_store(fe5 (&v)[16], const PassArgs& a, ui
                 }
             };
             issue(0);
-            ntt_dif_reg<4, 0, INV>(v);
+            ntt_dif_reg<4, 0, false>(v);
 #pragma clang loop unroll(full)
             for (int bt = 0; bt < 16 / B; bt++) {
                 if (bt + 1 < 16 / B) issue(bt + 1);
@@ -481,7 +498,9 @@ hipError_t launch_ntt_plane(const PassArgs& a, int32_t* plane, hipStream_t s)
 // applied to this pass's outputs, so every element leaves such a pass through a
 // multiplication, which is what brings the lazy limbs back to a canonical
 // value; the last pass has nothing to multiply by (the inverse's n^-1 rides on
-// the lo table) and reduces its lazy outputs directly (finish_lazy).
+// its exchange twiddles) and reduces its lazy outputs directly (finish_lazy).
+// Both directions run the forward root's butterflies and tables: an inverse
+// transform differs in its last pass only (INV), which stores in reversed order.
 // One workgroup per tile; three workgroups are resident per CU (168 registers,
 // 48-52 KiB of LDS each) and hide one another's memory and barrier waits.
 template <int RA, int MODE, bool TWIST, int NEXT_LAST, bool SMALL, bool INV>
@@ -496,13 +515,13 @@ __global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(3,
     const uint64_t tile = blockIdx.x;
     fe raw[16];
     fe5 v[16];
-    load_tile<RA, MODE, SMALL>(raw, a, tile, t);
+    load_tile<RA, MODE, SMALL, INV>(raw, a, tile, t);
     unpack_tile<RA, MODE, TWIST, SMALL>(v, raw, a, tile, t);
     // RA = 0 (radix 16, first pass only): load_tile has already put the 16 points of column t into this
     // thread's registers, which is the layout round 2 starts from: no first round, no exchange
     if constexpr (RA > 0) {
         lds_barrier();          // s_tw256 staged
-        round1_exchange<RA, MODE, INV>(v, lds, s_tw256, t);
+        round1_exchange<RA, MODE>(v, lds, s_tw256, t);
     }
     round2_store<RA, MODE, NEXT_LAST, SMALL, INV>(v, a, tile, t);
 }
@@ -520,11 +539,11 @@ static hipError_t launch_dir(const PassArgs& a, hipStream_t s)
 template <int RA, int MODE, bool TWIST, int NEXT_LAST, bool SMALL>
 static hipError_t launch_one(const PassArgs& a, hipStream_t s)
 {
-    // the butterfly constants are those of the forward root or of its inverse; a coset twist only
-    // ever precedes a forward transform
+    // an inverse transform is the forward one with its outputs stored in reversed order: only its last
+    // pass differs; a coset twist only ever precedes a forward transform
     if (a.inverse) {
         if constexpr (TWIST) return hipErrorInvalidValue;
-        else return launch_dir<RA, MODE, TWIST, NEXT_LAST, SMALL, true>(a, s);
+        else if constexpr (MODE == PASS_LAST) return launch_dir<RA, MODE, TWIST, NEXT_LAST, SMALL, true>(a, s);
     }
     return launch_dir<RA, MODE, TWIST, NEXT_LAST, SMALL, false>(a, s);
 }
