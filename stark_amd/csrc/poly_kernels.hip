@@ -134,25 +134,36 @@ __global__ __launch_bounds__(MPOLY_THREADS) void mpoly_eval_kernel(MPolyArgs a)
     // The arithmetic is the transform passes' lazy five-limb core (219 cycles a product against 391 on two
     // 64-bit words).  Values live scaled by 2^156, the factor a five-limb product divides by, so products of
     // scaled values are scaled values; the last product, by mul[i] or by 1 unscaled, takes the factor out.
-    __shared__ fe5 pt[MPOLY_MAX_VARS][MPOLY_THREADS];
+    // pt[v * MPOLY_THREADS + t]: sized by the launch for the variables there are, so that a polynomial in
+    // nine variables leaves room for six workgroups on a CU instead of the three that sixteen would
+    extern __shared__ fe5 pt[];
     const uint32_t t = threadIdx.x;
     const uint64_t i = (uint64_t)blockIdx.x * MPOLY_THREADS + t;
     if (i >= a.n) return;
     for (uint32_t v = 0; v < a.n_vars; v++) {
         uint64_t idx = i + a.rot[v];
         if (idx >= a.n) idx -= a.n;
-        pt[v][t] = mont_mul5_s(unpack5(a.cols[v][idx]), a.scale_in);
+        pt[v * MPOLY_THREADS + t] = mont_mul5_s(unpack5(a.cols[v][idx]), a.scale_in);
     }
     fe5 acc{{0, 0, 0, 0, 0}};
     uint32_t pending = 0;
+    // A term's sixteen exponent bytes are ONE 16-byte row, the same for every thread: it is fetched whole
+    // (a scalar load) one term ahead and taken apart with scalar shifts.  Read a byte at a time the
+    // exponents cost a vector-memory round trip per variable and term, several times the arithmetic.
+    static_assert(MPOLY_MAX_VARS == 16, "one exponent row is one uint4");
+    const uint4* __restrict__ rows = (const uint4*)a.exps;
+    uint4 row_next = a.n_terms ? rows[0] : uint4{0, 0, 0, 0};
     for (uint32_t k = 0; k < a.n_terms; k++) {
         bool started = false;
         fe5 prod{};
-        const uint8_t* __restrict__ ex = a.exps + (size_t)k * MPOLY_MAX_VARS;
+        const uint4 row = row_next;
+        if (k + 1 < a.n_terms) row_next = rows[k + 1];
+        const tw5 c = a.coef5[k];                  // scalar too; asked for here, needed after the powers
+        const uint64_t ex_lo = (uint64_t)row.x | ((uint64_t)row.y << 32), ex_hi = (uint64_t)row.z | ((uint64_t)row.w << 32);
         for (uint32_t v = 0; v < a.n_vars; v++) {
-            uint32_t e = ex[v];
+            const uint32_t e = (uint32_t)((v < 8 ? ex_lo >> (8 * v) : ex_hi >> (8 * (v - 8))) & 0xff);
             if (e == 0) continue;
-            const fe5 b = pt[v][t];
+            const fe5 b = pt[v * MPOLY_THREADS + t];
             // left-to-right over the bits of e: e is small (the AIR's degree)
             fe5 p = b;
             int top = 31 - __builtin_clz(e);
@@ -163,8 +174,7 @@ __global__ __launch_bounds__(MPOLY_THREADS) void mpoly_eval_kernel(MPolyArgs a)
             prod = started ? mont_mul5_v(prod, p) : p;
             started = true;
         }
-        // the coefficient last: it is the same for every thread and is read through the scalar path
-        const tw5 c = a.coef5[k];
+        // the coefficient last
         prod = started ? mont_mul5_s(prod, c) : fe5{{c.l[0], c.l[1], c.l[2], c.l[3], c.l[4]}};
         acc = add5(acc, prod);
         if (++pending == MPOLY_LAZY_TERMS) {
@@ -182,7 +192,7 @@ hipError_t launch_mpoly_eval(const MPolyArgs& a, hipStream_t s)
     if (a.n == 0) return hipSuccess;
     if (a.n_vars > MPOLY_MAX_VARS) return hipErrorInvalidValue;
     hipLaunchKernelGGL(mpoly_eval_kernel, dim3((uint32_t)((a.n + MPOLY_THREADS - 1) / MPOLY_THREADS)), dim3(MPOLY_THREADS),
-                       0, s, a);
+                       (size_t)a.n_vars * MPOLY_THREADS * sizeof(fe5), s, a);
     return hipGetLastError();
 }
 
