@@ -41,49 +41,60 @@ hipError_t launch_compose_linear(fe* data, uint64_t n, uint64_t n_cols, uint64_t
 }
 
 // x^(p-2) for x in Montgomery form (FieldElement::inverse, field.rs:67-93, by Fermat).
-// p - 2 = 0xCB7F_FFFF_..._FFFF: the top byte 0xCB, then 0x7F, then 112 one bits.
-__device__ __forceinline__ fe mont_inverse(fe xm, fe one_m)
+// p - 2 = 406 * 2^119 + (2^119 - 1): the nine bits of 406, then 119 one bits, which are taken seven at a
+// time with x^127: 133 squarings and 25 multiplications instead of the 128 + 120 of bit-by-bit.
+__device__ __forceinline__ fe mont_inverse(fe xm)
 {
-    // x^(2^k - 1) ladder for the long run of ones
-    fe r = one_m;
-    const u128 e = ((u128)0xCB7FFFFFFFFFFFFFull << 64) | 0xFFFFFFFFFFFFFFFFull;
-    for (int i = 127; i >= 0; i--) {
+    // x^(2^k - 1) for k = 2, 3, 6, 7
+    fe a = mont_mul(mont_mul(xm, xm), xm);                       // x^3
+    a = mont_mul(mont_mul(a, a), xm);                            // x^7
+    fe b = a;
+    for (int i = 0; i < 3; i++) b = mont_mul(b, b);
+    b = mont_mul(b, a);                                          // x^63
+    const fe x127 = mont_mul(mont_mul(b, b), xm);
+    // x^406, 406 = 0b110010110
+    fe r = xm;
+    for (int bit = 7; bit >= 0; bit--) {
         r = mont_mul(r, r);
-        if ((e >> i) & 1) r = mont_mul(r, xm);
+        if ((406 >> bit) & 1) r = mont_mul(r, xm);
+    }
+    for (int w = 0; w < 17; w++) {                               // 119 = 17 * 7 one bits
+        for (int i = 0; i < 7; i++) r = mont_mul(r, r);
+        r = mont_mul(r, x127);
     }
     return r;
 }
 
 // out[i] = 1 / a[i], 0 for 0 (the reference's inverse(0) is 0).  Each thread
 // inverts INV_K elements with one field inversion (Montgomery's trick): prefix
-// products, one Fermat power, and two multiplications per element on the way
-// back.  Element k of thread t in block b is b*INV_K*256 + k*256 + t, so every
+// products, one Fermat power (158 products shared by the INV_K elements), and three
+// multiplications per element on the way back, for which the element is read a second time rather
+// than kept in registers.  Element k of thread t in block b is b*INV_K*256 + k*256 + t, so every
 // access of a wave is contiguous.
-constexpr int INV_K = 8;
-__global__ __launch_bounds__(256) void vec_inv_kernel(const fe* __restrict__ a, fe* __restrict__ out, uint64_t n,
-                                                      fe r2, fe one_m)
+constexpr int INV_K = 16;
+// (a and out may be the same vector: a thread reads an element for the second time before it writes it)
+__global__ __launch_bounds__(256) void vec_inv_kernel(const fe* a, fe* out, uint64_t n, fe r2, fe one_m)
 {
     const uint64_t base = (uint64_t)blockIdx.x * (INV_K * 256) + threadIdx.x;
-    fe x[INV_K], pre[INV_K];
+    fe pre[INV_K];
     fe acc = one_m;
 #pragma unroll
     for (int k = 0; k < INV_K; k++) {
         const uint64_t i = base + (uint64_t)k * 256;
         fe v = fe_zero();
         if (i < n) v = a[i];
-        x[k] = fe_is_zero(v) ? one_m : mont_mul(v, r2);      // Montgomery form; zeros (and the tail) ride along as 1
         pre[k] = acc;
-        acc = mont_mul(acc, x[k]);
-        if (fe_is_zero(v)) x[k] = fe_zero();                 // remembered as a zero for the way back
+        if (!fe_is_zero(v)) acc = mont_mul(acc, mont_mul(v, r2));      // zeros (and the tail) ride along as 1
     }
-    fe inv = mont_inverse(acc, one_m);
+    fe inv = mont_inverse(acc);
 #pragma unroll
     for (int k = INV_K - 1; k >= 0; k--) {
         const uint64_t i = base + (uint64_t)k * 256;
-        const bool zero = fe_is_zero(x[k]);
-        const fe xi = zero ? one_m : x[k];
+        fe v = fe_zero();
+        if (i < n) v = a[i];
+        const bool zero = fe_is_zero(v);
         const fe r = mont_mul(inv, pre[k]);                  // (1/x_k) in Montgomery form
-        inv = mont_mul(inv, xi);
+        if (!zero) inv = mont_mul(inv, mont_mul(v, r2));
         if (i < n) out[i] = zero ? fe_zero() : mont_mul(r, fe{1, 0});
     }
 }

@@ -54,7 +54,7 @@ def _vec(n, seed, zeros=()):
 
 
 # ---- the device passes ----------------------------------------------------------------------------
-@pytest.mark.parametrize("n", [1, 7, 256, 2049, 1 << 16])
+@pytest.mark.parametrize("n", [1, 7, 256, 2049, 4096, 4097, 1 << 16])
 def test_vec_inv(ctx, n):
     """FieldElement::inverse (field.rs:67-93) pointwise, zero to zero."""
     x = _vec(n, 40 + n, zeros=[0, n // 2] if n > 2 else [])
