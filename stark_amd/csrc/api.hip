@@ -1331,7 +1331,7 @@ extern "C" int32_t stark_sample_bytes_dev(stark_ctx* ctx, const uint8_t* bytes_d
     CtxGuard guard_(ctx);
     if (!ctx || (n && (!bytes_dev || !out_dev))) return fail(STARK_EARG, "null argument");
     if (width == 0 || width > 0xFFFFFFFFull) return fail(STARK_ELENGTH, "byte strings must be 1 .. 2^32-1 bytes long");
-    HIP_TRY(launch_sample_bytes(bytes_dev, (uint32_t)width, (fe*)out_dev, n, ctx->F.to_mont(fe{256, 0}),
+    HIP_TRY(launch_sample_bytes(bytes_dev, (uint32_t)width, (fe*)out_dev, n, ctx->F.to_mont(fe{0, (u64)1 << 56}),
                                 reversed != 0, ctx->stream));
     return STARK_OK;
 }

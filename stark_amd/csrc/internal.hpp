@@ -192,7 +192,7 @@ hipError_t launch_mpoly_eval(const MPolyArgs& a, hipStream_t s);
 // *result_dev (zeroed by the caller) = 1 + largest index of a nonzero coefficient, 0 if none
 hipError_t launch_poly_degree(const fe* c, uint64_t n, unsigned long long* result_dev, hipStream_t s);
 // out[i] (out[n-1-i] if reversed) = big-endian integer of bytes[i*width .. (i+1)*width) modulo p
-hipError_t launch_sample_bytes(const uint8_t* bytes, uint32_t width, fe* out, uint64_t n, fe c256_m, bool reversed,
+hipError_t launch_sample_bytes(const uint8_t* bytes, uint32_t width, fe* out, uint64_t n, fe c120_m, bool reversed,
                                hipStream_t s);
 
 }  // namespace starkk

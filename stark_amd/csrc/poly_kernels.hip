@@ -280,29 +280,39 @@ hipError_t launch_poly_degree(const fe* c, uint64_t n, unsigned long long* resul
 }
 
 // FieldElement::sample (field.rs:110-116) of n byte strings of `width` bytes each:
-// the big-endian integer of the bytes modulo p, accumulated byte by byte as the
-// reference does.  The randomizer coefficients of stark.rs:345-351 from their
-// raw random bytes.  c256_m = 256 in Montgomery form.  With `reversed` string i
-// lands at out[n-1-i]: the reference fills Polynomial::coeffs, which is highest
-// degree first (univariate_poly.rs:27), in drawing order.
+// the big-endian integer of the bytes modulo p.  The reference reduces after every byte; the value is
+// the same taken fifteen bytes at a time (120 bits, below p): acc = acc * 2^120 + chunk, one product
+// per chunk instead of one per byte (a leading chunk of width mod 15 bytes first).  The randomizer
+// coefficients of stark.rs:345-351 from their raw random bytes.  c120_m = 2^120 in Montgomery form.
+// With `reversed` string i lands at out[n-1-i]: the reference fills Polynomial::coeffs, which is
+// highest degree first (univariate_poly.rs:27), in drawing order.
 __global__ __launch_bounds__(256) void sample_bytes_kernel(const uint8_t* __restrict__ bytes, uint32_t width,
-                                                           fe* __restrict__ out, uint64_t n, fe c256_m, int reversed)
+                                                           fe* __restrict__ out, uint64_t n, fe c120_m, int reversed)
 {
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const uint8_t* p = bytes + i * width;
+    uint32_t take = width % 15;
+    if (take == 0) take = 15;
     fe acc = fe_zero();
-    for (uint32_t k = 0; k < width; k++) acc = fe_add(mont_mul(acc, c256_m), fe{p[k], 0});
+    for (uint32_t k = 0; k < width; k += take, take = 15) {
+        uint64_t hi = 0, lo = 0;                               // the chunk's integer, below 2^120
+        for (uint32_t b = 0; b < take; b++) {
+            hi = (hi << 8) | (lo >> 56);
+            lo = (lo << 8) | p[k + b];
+        }
+        acc = fe_add(mont_mul(acc, c120_m), fe{lo, hi});
+    }
     out[reversed ? n - 1 - i : i] = acc;
 }
 
-hipError_t launch_sample_bytes(const uint8_t* bytes, uint32_t width, fe* out, uint64_t n, fe c256_m, bool reversed,
+hipError_t launch_sample_bytes(const uint8_t* bytes, uint32_t width, fe* out, uint64_t n, fe c120_m, bool reversed,
                                hipStream_t s)
 {
     if (n == 0) return hipSuccess;
     if (width == 0) return hipErrorInvalidValue;
     hipLaunchKernelGGL(sample_bytes_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, bytes, width, out, n,
-                       c256_m, reversed ? 1 : 0);
+                       c120_m, reversed ? 1 : 0);
     return hipGetLastError();
 }
 

@@ -216,7 +216,7 @@ def test_poly_eval_points(ctx, n, polys, pad):
         ctx.poly_eval_points_dev(_dev(c), n, [P], n_polys=polys, stride=stride)
 
 
-@pytest.mark.parametrize("width,n", [(17, 1000), (32, 257), (1, 5), (40, 64)])
+@pytest.mark.parametrize("width,n", [(17, 1000), (32, 257), (1, 5), (40, 64), (14, 70), (15, 300), (16, 300), (30, 65), (45, 33)])
 def test_sample_bytes(ctx, width, n):
     """FieldElement::sample (field.rs:110-116) of n byte strings; reversed as Polynomial::coeffs is filled."""
     import torch
