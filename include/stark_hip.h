@@ -74,6 +74,8 @@ int32_t stark_dev_alloc(stark_ctx* ctx, size_t bytes, void** dptr);
 int32_t stark_dev_free(stark_ctx* ctx, void* dptr);
 int32_t stark_copy_h2d(stark_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
 int32_t stark_copy_d2h(stark_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+/* Device to device on the context's stream, not synchronised (Vec::clone of a resident vector, fri.rs:130). */
+int32_t stark_copy_d2d(stark_ctx* ctx, void* dst_dev, const void* src_dev, size_t bytes);
 
 /* ---- NTT ------------------------------------------------------------------
  * NTT::forward / NTT::inverse (ntt.rs:25-40): in place, natural order in and
@@ -137,8 +139,10 @@ int32_t stark_poly_lincomb_dev(stark_ctx* ctx, size_t n_terms, const uint64_t* c
  * cols_dev is a host array of n_vars <= 16 device pointers, rotations (may be
  * NULL) turns a column of values on offset*omega^i into the values of the
  * polynomial composed with omega^rot * x; coeffs (2 words each) and exps (one
- * byte each) are host arrays.  If mul_dev is not NULL the result is multiplied
- * by mul_dev[i] (a zeroifier's inverse values, stark.rs:336-341).  Synchronises. */
+ * byte each) are host arrays (copied before the call returns).  If mul_dev is
+ * not NULL the result is multiplied by mul_dev[i] (a zeroifier's inverse values,
+ * stark.rs:336-341).  Not synchronised while the term table fits 16 KiB (about
+ * 450 terms); a longer table drains the stream. */
 int32_t stark_mpoly_eval_dev(stark_ctx* ctx, size_t n_vars, const uint64_t* const* cols_dev, const size_t* rotations,
                              size_t n_terms, const uint64_t* coeffs, const uint8_t* exps, const uint64_t* mul_dev,
                              uint64_t* out_dev, size_t n);
@@ -147,6 +151,10 @@ int32_t stark_mpoly_eval_dev(stark_ctx* ctx, size_t n_vars, const uint64_t* cons
  * (*is_zero_out, if not NULL, tells the two apart).  Synchronises. */
 int32_t stark_poly_degree_dev(stark_ctx* ctx, const uint64_t* coeffs_dev, size_t n, size_t* degree_out,
                               int32_t* is_zero_out);
+/* The same without the wait, for a prover that checks its degree assertions
+ * (stark.rs:379-380) once at the end: *result_dev (8 bytes of device memory)
+ * receives 0 for the zero polynomial, else degree + 1.  Not synchronised. */
+int32_t stark_poly_degree_post_dev(stark_ctx* ctx, const uint64_t* coeffs_dev, size_t n, uint64_t* result_dev);
 /* Polynomial::eval (univariate_poly.rs:87-96) of n_polys polynomials of n coefficients each (lowest degree
  * first, polynomial q at coeffs_dev + 2*q*stride words) at n_points <= 16 points given on the host:
  * out[q * n_points + p] = polynomial q at points[p] (host memory).  The verifier's evaluations of long

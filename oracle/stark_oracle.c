@@ -31,6 +31,14 @@
 typedef unsigned __int128 u128;
 typedef uint64_t u64;
 
+/* Worker threads for the bulk loops (leaf and node hashing, fold, butterflies).  1 = the plain
+ * sequential loops; more only changes who computes which element (the all-cores CPU baseline),
+ * never a value: tests/ compare the two. */
+static int g_threads = 1;
+void so_set_threads(int t) { g_threads = t < 1 ? 1 : t; }
+int so_get_threads(void) { return g_threads; }
+#define PAR_FOR _Pragma("omp parallel for schedule(static) num_threads(g_threads) if (g_threads > 1)")
+
 /* ------------------------------------------------------------------------ */
 /* field.rs                                                                  */
 /* ------------------------------------------------------------------------ */
@@ -186,17 +194,54 @@ static void bit_reverse(u128 *a, size_t n)         /* ntt.rs:74-88 */
     }
 }
 
+/* the same permutation with every index reversed by itself, so that threads can share the loop */
+static void bit_reverse_mt(u128 *a, size_t n)
+{
+    int bits = 0;
+    while (((size_t)1 << bits) < n) bits++;
+    PAR_FOR
+    for (size_t i = 1; i < n; i++) {
+        size_t j = 0;
+        for (int b = 0; b < bits; b++) j |= ((i >> b) & 1) << (bits - 1 - b);
+        if (i < j) { u128 t = a[i]; a[i] = a[j]; a[j] = t; }
+    }
+}
+
+static u128 fe_pow(u128 base, u128 exp);
+
 /* ntt.rs:43-71.  Same loop nest and the same running-product twiddle; the
- * twiddle is kept in Montgomery form so each butterfly costs one reduction. */
+ * twiddle is kept in Montgomery form so each butterfly costs one reduction.
+ * With more than one thread a stage is cut into runs of butterflies, each
+ * starting its running product at the power it would have reached. */
+#define NTT_RUN 2048
 static void ntt_core(u128 *a, size_t n, u128 omega)
 {
     if (n <= 1) return;
-    bit_reverse(a, n);
+    if (g_threads > 1) bit_reverse_mt(a, n); else bit_reverse(a, n);
     u128 one_m = to_mont(1);
     for (size_t len = 2; len <= n; len <<= 1) {
-        u128 w_m = to_mont(fe_pow(omega, n / len));
+        u128 w = fe_pow(omega, n / len);
+        u128 w_m = to_mont(w);
         size_t half = len >> 1;
-        for (size_t i = 0; i < n; i += len) {
+        if (g_threads > 1 && half >= NTT_RUN) {
+            size_t runs_per_block = half / NTT_RUN, items = (n / len) * runs_per_block;
+            PAR_FOR
+            for (size_t t = 0; t < items; t++) {
+                size_t i = (t / runs_per_block) * len, j0 = (t % runs_per_block) * NTT_RUN;
+                u128 wn_m = to_mont(fe_pow(w, j0));
+                for (size_t j = j0; j < j0 + NTT_RUN; j++) {
+                    u128 u = a[i + j];
+                    u128 v = mont_mul(a[i + j + half], wn_m);
+                    a[i + j] = fe_add(u, v);
+                    a[i + j + half] = fe_sub(u, v);
+                    wn_m = mont_mul(wn_m, w_m);
+                }
+            }
+            continue;
+        }
+        PAR_FOR
+        for (size_t b = 0; b < n / len; b++) {
+            size_t i = b * len;
             u128 wn_m = one_m;
             for (size_t j = 0; j < half; j++) {
                 u128 u = a[i + j];
@@ -222,6 +267,7 @@ int so_ntt(u64 *data, size_t n, int inverse)
     if (inverse) {
         ntt_core(a, n, fe_inverse(omega));
         u128 n_inv_m = to_mont(fe_inverse((u128)n));
+        PAR_FOR
         for (size_t i = 0; i < n; i++) a[i] = mont_mul(a[i], n_inv_m);
     } else {
         ntt_core(a, n, omega);
@@ -432,6 +478,7 @@ static void merkle_reduce(uint8_t *tree, size_t n)
     uint8_t *cur = tree;
     for (size_t m = n; m > 1; m >>= 1) {
         uint8_t *nxt = cur + m * 32;
+        PAR_FOR
         for (size_t i = 0; i < m / 2; i++) so_blake2b(cur + 64 * i, 64, nxt + 32 * i, 32);   /* merkle.rs:29-32 */
         cur = nxt;
     }
@@ -441,8 +488,9 @@ static void merkle_reduce(uint8_t *tree, size_t n)
 int so_merkle_tree_fe(const u64 *elems, size_t n, uint8_t *tree)
 {
     if (n == 0 || (n & (n - 1))) return -1;       /* "length must be power of two" */
-    uint8_t leaf[25];
+    PAR_FOR
     for (size_t i = 0; i < n; i++) {
+        uint8_t leaf[25];
         size_t len = so_bincode_fe(elems + 2 * i, leaf);
         so_blake2b(leaf, len, tree + 32 * i, 32);                /* merkle.rs:41-47 */
     }
@@ -599,13 +647,20 @@ void so_fri_fold(const u64 *cw, size_t N, const u64 alpha[2], const u64 offset[2
     u128 two_inv_m = to_mont(two_inv);
     u128 c_m = to_mont(fe_mul(fe_mul(two_inv, ld(alpha)), fe_inverse(ld(offset))));
     u128 winv_m = to_mont(fe_inverse(ld(omega)));
-    u128 wi_m = to_mont(1);                        /* omega^-i, Montgomery form */
-    for (size_t i = 0; i < half; i++) {
-        u128 a = ld(cw + 2 * i), b = ld(cw + 2 * (half + i));
-        u128 s = mont_mul(fe_add(a, b), two_inv_m);
-        u128 d = mont_mul(fe_sub(a, b), mont_mul(wi_m, c_m));
-        st(out + 2 * i, fe_add(s, d));
-        wi_m = mont_mul(wi_m, winv_m);
+    u128 winv = fe_inverse(ld(omega));
+    /* runs of outputs, each starting omega^-i at its own power (one run per 4096 outputs) */
+    size_t run = 4096, runs = (half + run - 1) / run;
+    PAR_FOR
+    for (size_t t = 0; t < runs; t++) {
+        size_t lo = t * run, hi = lo + run < half ? lo + run : half;
+        u128 wi_m = to_mont(fe_pow(winv, lo));     /* omega^-i, Montgomery form */
+        for (size_t i = lo; i < hi; i++) {
+            u128 a = ld(cw + 2 * i), b = ld(cw + 2 * (half + i));
+            u128 s = mont_mul(fe_add(a, b), two_inv_m);
+            u128 d = mont_mul(fe_sub(a, b), mont_mul(wi_m, c_m));
+            st(out + 2 * i, fe_add(s, d));
+            wi_m = mont_mul(wi_m, winv_m);
+        }
     }
 }
 

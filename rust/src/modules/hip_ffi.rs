@@ -41,6 +41,7 @@ extern "C" {
     pub fn stark_dev_free(ctx: *mut StarkCtx, dptr: *mut c_void) -> i32;
     pub fn stark_copy_h2d(ctx: *mut StarkCtx, dst_dev: *mut c_void, src_host: *const c_void, bytes: usize) -> i32;
     pub fn stark_copy_d2h(ctx: *mut StarkCtx, dst_host: *mut c_void, src_dev: *const c_void, bytes: usize) -> i32;
+    pub fn stark_copy_d2d(ctx: *mut StarkCtx, dst_dev: *mut c_void, src_dev: *const c_void, bytes: usize) -> i32;
     pub fn stark_ntt(ctx: *mut StarkCtx, data: *mut u64, n: usize, inverse: i32) -> i32;
     pub fn stark_ntt_dev(ctx: *mut StarkCtx, data_dev: *mut u64, n: usize, inverse: i32) -> i32;
     pub fn stark_ntt_batch(ctx: *mut StarkCtx, data: *mut u64, n: usize, n_cols: usize, col_stride: usize,
@@ -67,6 +68,7 @@ extern "C" {
                                 mul_dev: *const u64, out_dev: *mut u64, n: usize) -> i32;
     pub fn stark_poly_degree_dev(ctx: *mut StarkCtx, coeffs_dev: *const u64, n: usize, degree_out: *mut usize,
                                  is_zero_out: *mut i32) -> i32;
+    pub fn stark_poly_degree_post_dev(ctx: *mut StarkCtx, coeffs_dev: *const u64, n: usize, result_dev: *mut u64) -> i32;
     pub fn stark_poly_eval_points_dev(ctx: *mut StarkCtx, coeffs_dev: *const u64, n: usize, n_polys: usize, stride: usize,
                                       points: *const u64, n_points: usize, out: *mut u64) -> i32;
     pub fn stark_sample_bytes_dev(ctx: *mut StarkCtx, bytes_dev: *const u8, width: usize, n: usize, reversed: i32,

@@ -32,6 +32,7 @@ SIGNATURES = {
     "stark_dev_free": (i32, [C.c_void_p, C.c_void_p]),
     "stark_copy_h2d": (i32, [C.c_void_p, C.c_void_p, C.c_void_p, sz]),
     "stark_copy_d2h": (i32, [C.c_void_p, C.c_void_p, C.c_void_p, sz]),
+    "stark_copy_d2d": (i32, [C.c_void_p, C.c_void_p, C.c_void_p, sz]),
     "stark_ntt": (i32, [C.c_void_p, C.c_void_p, sz, i32]),
     "stark_ntt_dev": (i32, [C.c_void_p, C.c_void_p, sz, i32]),
     "stark_ntt_batch": (i32, [C.c_void_p, C.c_void_p, sz, sz, sz, i32]),
@@ -45,6 +46,7 @@ SIGNATURES = {
     "stark_mpoly_eval_dev": (i32, [C.c_void_p, sz, C.c_void_p, C.c_void_p, sz, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p, sz]),
     "stark_poly_degree_dev": (i32, [C.c_void_p, C.c_void_p, sz, szp, C.POINTER(i32)]),
+    "stark_poly_degree_post_dev": (i32, [C.c_void_p, C.c_void_p, sz, C.c_void_p]),
     "stark_sample_bytes_dev": (i32, [C.c_void_p, C.c_void_p, sz, sz, i32, C.c_void_p]),
     "stark_fourstep_twiddle_dev": (i32, [C.c_void_p, C.c_void_p, sz, sz, sz, sz, i32]),
     "stark_fourstep_pack_dev": (i32, [C.c_void_p, C.c_void_p, sz, sz, sz, sz, sz, i32, C.c_void_p]),

@@ -118,6 +118,20 @@ struct stark_ctx {
     };
     std::vector<Lane> lanes;
     hipEvent_t lane_gate = nullptr;
+    // Small tables that go up with a launch (the term table of a constraint): a ring of slots, each a pinned
+    // host block, its device twin and an event recorded behind the kernel that reads the twin.  A call fills the
+    // next slot and waits only if that slot's previous kernel has not finished, so the call itself never
+    // drains the stream.
+    struct SmallSlot {
+        void* pin = nullptr;
+        void* dev = nullptr;
+        hipEvent_t done = nullptr;
+        bool pending = false;
+    };
+    static constexpr size_t SMALL_SLOT_BYTES = 16384;
+    static constexpr size_t SMALL_SLOTS = 8;
+    SmallSlot small[SMALL_SLOTS];
+    size_t small_next = 0;
 };
 
 struct stark_tree {
@@ -680,6 +694,38 @@ static hipError_t copy_out(stark_ctx* ctx, void* dst_host, const void* src_dev, 
     return (hipError_t)err.load();
 }
 
+// Takes the next slot of the context's ring for `bytes` <= SMALL_SLOT_BYTES of host data, queues their copy to
+// the slot's device block on the context's stream and returns the slot; the caller launches the kernel that
+// reads slot->dev and then calls small_slot_done.
+static hipError_t small_slot_stage(stark_ctx* ctx, const void* src, size_t bytes, stark_ctx::SmallSlot** out)
+{
+    stark_ctx::SmallSlot& sl = ctx->small[ctx->small_next];
+    ctx->small_next = (ctx->small_next + 1) % stark_ctx::SMALL_SLOTS;
+    hipError_t e = hipSuccess;
+    if (!sl.pin) {
+        e = hipHostMalloc(&sl.pin, stark_ctx::SMALL_SLOT_BYTES, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipMalloc(&sl.dev, stark_ctx::SMALL_SLOT_BYTES);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.done, hipEventDisableTiming);
+        if (e != hipSuccess) return e;
+    }
+    if (sl.pending) {
+        e = hipEventSynchronize(sl.done);
+        if (e != hipSuccess) return e;
+        sl.pending = false;
+    }
+    memcpy(sl.pin, src, bytes);
+    e = hipMemcpyAsync(sl.dev, sl.pin, bytes, hipMemcpyHostToDevice, ctx->stream);
+    *out = &sl;
+    return e;
+}
+
+static hipError_t small_slot_done(stark_ctx* ctx, stark_ctx::SmallSlot* sl)
+{
+    hipError_t e = hipEventRecord(sl->done, ctx->stream);
+    sl->pending = e == hipSuccess;
+    return e;
+}
+
 struct DevBuf {
     stark_ctx* ctx;
     void* p = nullptr;
@@ -898,6 +944,11 @@ extern "C" void stark_ctx_destroy(stark_ctx* ctx)
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->pin_io) (void)hipHostFree(ctx->pin_io);
     lanes_destroy(ctx);
+    for (auto& sl : ctx->small) {
+        if (sl.pin) (void)hipHostFree(sl.pin);
+        if (sl.dev) (void)hipFree(sl.dev);
+        if (sl.done) (void)hipEventDestroy(sl.done);
+    }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -988,6 +1039,14 @@ extern "C" int32_t stark_copy_d2h(stark_ctx* ctx, void* dst_host, const void* sr
     if (!ctx) return fail(STARK_EARG, "null context");
     HIP_TRY(copy_out(ctx, dst_host, src_dev, bytes));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return STARK_OK;
+}
+
+extern "C" int32_t stark_copy_d2d(stark_ctx* ctx, void* dst_dev, const void* src_dev, size_t bytes)
+{
+    CtxGuard guard_(ctx);
+    if (!ctx || (bytes && (!dst_dev || !src_dev))) return fail(STARK_EARG, "null argument");
+    if (bytes) HIP_TRY(hipMemcpyAsync(dst_dev, src_dev, bytes, hipMemcpyDeviceToDevice, ctx->stream));
     return STARK_OK;
 }
 
@@ -1229,12 +1288,23 @@ extern "C" int32_t stark_mpoly_eval_dev(stark_ctx* ctx, size_t n_vars, const uin
         memcpy(table.data() + k * sizeof(tw5), &cm, sizeof(tw5));
         for (size_t v = 0; v < n_vars; v++) table[coef_bytes + k * MPOLY_MAX_VARS + v] = exps[k * n_vars + v];
     }
+    // small tables (the usual case: a few dozen terms) travel through the context's ring of staging slots and the
+    // call returns with everything queued; a table too large for a slot goes up from pageable memory and the
+    // stream is drained before that memory and its device block go away
     DevBuf tb(ctx);
-    ST_TRY(tb.alloc(table.size()));
-    HIP_TRY(hipMemcpyAsync(tb.p, table.data(), table.size(), hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));              // `table` is pageable host memory about to go away
-    a.coef5 = (const tw5*)tb.p;
-    a.exps = (const uint8_t*)tb.p + coef_bytes;
+    stark_ctx::SmallSlot* slot = nullptr;
+    const uint8_t* table_dev;
+    if (table.size() <= stark_ctx::SMALL_SLOT_BYTES) {
+        HIP_TRY(small_slot_stage(ctx, table.data(), table.size(), &slot));
+        table_dev = (const uint8_t*)slot->dev;
+    } else {
+        ST_TRY(tb.alloc(table.size()));
+        HIP_TRY(hipMemcpyAsync(tb.p, table.data(), table.size(), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        table_dev = (const uint8_t*)tb.p;
+    }
+    a.coef5 = (const tw5*)table_dev;
+    a.exps = table_dev + coef_bytes;
     a.mul = (const fe*)mul_dev;
     a.out = (fe*)out_dev;
     a.n = n;
@@ -1247,7 +1317,20 @@ extern "C" int32_t stark_mpoly_eval_dev(stark_ctx* ctx, size_t n_vars, const uin
         a.scale_in = to_tw5(ctx->F, r156);
     }
     HIP_TRY(launch_mpoly_eval(a, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));              // the table block returns to the cache on return
+    if (slot)
+        HIP_TRY(small_slot_done(ctx, slot));
+    else
+        HIP_TRY(hipStreamSynchronize(ctx->stream));          // the table block returns to the cache on return
+    return STARK_OK;
+}
+
+// stark_poly_degree_dev without the wait: 0 for the zero polynomial, else degree + 1, left in device memory
+extern "C" int32_t stark_poly_degree_post_dev(stark_ctx* ctx, const uint64_t* coeffs_dev, size_t n, uint64_t* result_dev)
+{
+    CtxGuard guard_(ctx);
+    if (!ctx || (n && !coeffs_dev) || !result_dev) return fail(STARK_EARG, "null argument");
+    HIP_TRY(hipMemsetAsync(result_dev, 0, sizeof(unsigned long long), ctx->stream));
+    HIP_TRY(launch_poly_degree((const fe*)coeffs_dev, n, (unsigned long long*)result_dev, ctx->stream));
     return STARK_OK;
 }
 

@@ -61,6 +61,8 @@ def _load():
         "so_fri_commit": (C.c_int, [u64p, sz, u64p, u64p, sz, sz, C.c_void_p, u64p, u8p, u64p]),
         "so_fri_sample_indices": (C.c_int, [u8p, sz, C.c_uint64, C.c_uint64, sz, u64p]),
         "so_splitmix_field_vector": (None, [u64p, sz, C.c_uint64]),
+        "so_set_threads": (None, [C.c_int]),
+        "so_get_threads": (C.c_int, []),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)
@@ -101,6 +103,22 @@ def from_ints(vals) -> np.ndarray:
 def to_ints(a: np.ndarray):
     b = np.ascontiguousarray(a).tobytes()
     return [int.from_bytes(b[i:i + 16], "little") for i in range(0, len(b), 16)]
+
+
+class threads:
+    """with threads(k): the bulk loops of the restatement (hashing, fold, butterflies) run on k threads.
+    The values do not depend on k; only the all-cores CPU baseline and its test use more than one."""
+
+    def __init__(self, k: int):
+        self.k = k
+
+    def __enter__(self):
+        self.prev = lib.so_get_threads()
+        lib.so_set_threads(self.k)
+        return self
+
+    def __exit__(self, *exc):
+        lib.so_set_threads(self.prev)
 
 
 def splitmix(n: int, seed: int = 0x5741524B) -> np.ndarray:

@@ -185,6 +185,20 @@ for wl, reps in WORKLOADS.items():
         entry["launches_per_call"] = launches / reps
         w("  per call: HBM-side traffic %.1f MB in %.1f launches, %.0f VALU wave-instructions" %
           (entry["traffic_bytes_per_call"] / 1e6, entry["launches_per_call"], entry["valu_wave_instr_per_call"]))
+        # the clock the chip held over the call's kernels and how busy the VALU pipes were (as for the transforms)
+        disp = pmc_dispatches(wl, "valu")
+        cyc = sum(x["SQ_BUSY_CYCLES"] for x in disp) / N_SE
+        dur = sum(x["dur_ns"] for x in disp)
+        entry["valu_issue"] = {
+            "busy_frac": round(4 * sum(x["SQ_ACTIVE_INST_VALU"] for x in disp) / (N_SIMD * cyc), 4),
+            "clock_ghz": round(cyc / dur, 3),
+            "kernel_ms_per_call": round(dur / reps / 1e6, 4),
+            "valu_ginstr_s_in_kernels": round(tot_valu / dur, 1)}
+        w("  VALU pipes busy %.0f %% of the kernels' cycles, clock held %.2f GHz, %.3f ms of kernel time per call: "
+          "%.0f Gwave-instr/s inside the kernels against 1024 x %.2f / 4 = %.0f at that clock and 614 at 2.4 GHz" %
+          (100 * entry["valu_issue"]["busy_frac"], entry["valu_issue"]["clock_ghz"], entry["valu_issue"]["kernel_ms_per_call"],
+           entry["valu_issue"]["valu_ginstr_s_in_kernels"], entry["valu_issue"]["clock_ghz"],
+           N_SIMD * entry["valu_issue"]["clock_ghz"] / 4))
     data[wl] = entry
 
 hb = os.path.join(raw, "hash_bench.txt")
