@@ -56,20 +56,31 @@ int32_t stark_ctx_create(int32_t device, stark_ctx** out);
 void stark_ctx_destroy(stark_ctx* ctx);
 /* A new context launches on a stream of its own.  stark_ctx_set_stream makes it
  * launch on the caller's hipStream_t instead (NULL = HIP's default stream);
- * stark_ctx_reset_stream goes back to the context's own stream. */
+ * stark_ctx_reset_stream goes back to the context's own stream.  Leaving a
+ * stream waits for the work the context queued on it, unless the stream left
+ * or the stream taken is being captured into a graph (no wait is allowed
+ * then): to capture, make one call of every size on the capturing stream
+ * before the capture begins (tables and scratch are built then), and do not
+ * leave work on another stream that the captured calls depend on. */
 int32_t stark_ctx_set_stream(stark_ctx* ctx, void* hip_stream);
 int32_t stark_ctx_reset_stream(stark_ctx* ctx);
 int32_t stark_ctx_synchronize(stark_ctx* ctx);
 /* Releases the device memory a context keeps between calls for speed (cached
  * scratch blocks of up to 8 GiB in total, the transform's ping buffer, twiddle
- * tables and planes); everything is rebuilt on next use.  The library also does
- * this by itself before it reports STARK_ENOMEM. */
+ * tables and planes); everything is rebuilt on next use.  When an allocation
+ * fails the library gives the cached scratch blocks back by itself and tries
+ * once more before it reports STARK_ENOMEM; the ping buffer, tables and planes
+ * are only released by this call. */
 int32_t stark_ctx_trim(stark_ctx* ctx);
 const char* stark_last_error(void);
 
 /* ---- device memory helpers (for callers that keep vectors resident) ------
  * Freed blocks stay in the context's cache for the next stark_dev_alloc of the
- * same size (stark_ctx_trim gives them back to the runtime). */
+ * same size (stark_ctx_trim gives them back to the runtime).  stark_dev_free
+ * waits for the context's stream only, and the next allocation (the caller's or
+ * the library's own scratch) may hand the block out at once: a caller who used
+ * the block on any other stream (a framework's stream, a second context) must
+ * wait for that work itself before freeing it. */
 int32_t stark_dev_alloc(stark_ctx* ctx, size_t bytes, void** dptr);
 int32_t stark_dev_free(stark_ctx* ctx, void* dptr);
 int32_t stark_copy_h2d(stark_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);

@@ -336,11 +336,11 @@ class ScaledStark:
             assert len(col) == self.original_trace_length - 1
         return [self.geo.interpolate(col) for col in constant_columns]
 
-    # ---- prover (:223-471)
-    def prove(self, trace: List[List[int]], air: Sequence[sp.MPolynomial], constant_columns: Sequence[Sequence[int]],
-              boundary: Boundary, rng: Callable[[int], bytes]) -> bytes:
+    # ---- prover (:223-471), in the steps a prover spread over several devices also runs: what happens off the
+    # FRI domain is in step_*; prove() adds the codewords, commitments, FRI and openings
+    def step_begin(self, trace: List[List[int]], boundary: Boundary, rng: Callable[[int], bytes]) -> dict:
+        """:237-288 -> {"trace_polynomials", "boundary_quotients", "n_rows"}"""
         trace = [list(row) for row in trace]
-        ps = so.ProofStream()
         for _ in range(self.num_randomizers):                                       # :237-253
             trace.append([so.fe_sample(rng(17)) for _ in range(self.num_registers)])
         n_rows = len(trace)
@@ -357,14 +357,13 @@ class ScaledStark:
         div_offset = fe_pow(self.generator, 3)
         boundary_quotients = [divide_exact(poly_sub(trace_polynomials[s], interpolants[s]), zeroifiers[s], div_offset)
                               for s in range(self.num_registers)]                   # :282-288
-        n_fri = self.fri_domain_length
-        bq_codewords, bq_trees = [], []
-        for s in range(self.num_registers):                                         # :293-306
-            cw = coset_eval(boundary_quotients[s], n_fri, self.generator)
-            tree = oc.merkle_tree_fe(oc.from_ints(cw))
-            bq_codewords.append(cw)
-            bq_trees.append(tree)
-            ps.push(tree[-1].tobytes().hex())
+        return {"trace_polynomials": trace_polynomials, "boundary_quotients": boundary_quotients, "n_rows": n_rows}
+
+    def step_transition(self, state: dict, air: Sequence[sp.MPolynomial], constant_columns: Sequence[Sequence[int]],
+                        rng: Callable[[int], bytes]) -> None:
+        """:309-353 -> state["transition_quotients"], state["randomizer_poly"]"""
+        trace_polynomials = state["trace_polynomials"]
+        div_offset = fe_pow(self.generator, 3)
         # transition polynomials (:309-333) by values on a coset of the omicron subgroup: the composition
         # with omicron * x (:319-325) is a rotation of the values
         max_degree = self.max_degree(air)
@@ -385,16 +384,19 @@ class ScaledStark:
             tq = coset_interpolate([v * z % P for v, z in zip(vals, tz_inv)], div_offset)
             assert all(c == 0 for c in tq[bound + 1:]) and tq[bound] != 0           # :379-380
             transition_quotients.append(tq[:bound + 1])
-        randomizer_poly = [so.fe_sample(rng(17)) for _ in range(max_degree + 1)][::-1]   # :344-353, drawn highest first
-        randomizer_codeword = coset_eval(randomizer_poly, n_fri, self.generator)    # :356-360
-        randomizer_tree = oc.merkle_tree_fe(oc.from_ints(randomizer_codeword))
-        ps.push(randomizer_tree[-1].tobytes().hex())
-        weights = so.sample_weights(1 + 2 * len(transition_quotients) + 2 * len(boundary_quotients),
-                                    ps.prover_fiat_shamir(32))                      # :372-376
-        terms: List[Tuple[List[int], int]] = [(randomizer_poly, 0)]                 # (polynomial, shift): x^shift * polynomial
+        state["transition_quotients"] = transition_quotients
+        state["randomizer_poly"] = [so.fe_sample(rng(17)) for _ in range(max_degree + 1)][::-1]   # :344-353, drawn highest first
+
+    def step_combine(self, state: dict, air: Sequence[sp.MPolynomial], boundary: Boundary, seed: bytes) -> List[int]:
+        """:372-404 -> the nonlinear combination's coefficients"""
+        max_degree = self.max_degree(air)
+        transition_quotients, boundary_quotients = state["transition_quotients"], state["boundary_quotients"]
+        tq_bounds = self.transition_quotient_degree_bounds(air)
+        weights = so.sample_weights(1 + 2 * len(transition_quotients) + 2 * len(boundary_quotients), seed)   # :372-376
+        terms: List[Tuple[List[int], int]] = [(state["randomizer_poly"], 0)]        # (polynomial, shift): x^shift * polynomial
         for tq, bound in zip(transition_quotients, tq_bounds):                      # :385-398
             terms += [(tq, 0), (tq, max_degree - bound)]
-        bq_bounds = self.boundary_quotient_degree_bounds(n_rows, boundary)
+        bq_bounds = self.boundary_quotient_degree_bounds(state["n_rows"], boundary)
         for bq, bound in zip(boundary_quotients, bq_bounds):
             terms += [(bq, 0), (bq, max_degree - bound)]
         combination = [0] * (max_degree + 1)                                        # :401-404
@@ -402,6 +404,26 @@ class ScaledStark:
             assert len(poly) + shift <= max_degree + 1
             for j, c in enumerate(poly):
                 combination[j + shift] = (combination[j + shift] + w * c) % P
+        return combination
+
+    def prove(self, trace: List[List[int]], air: Sequence[sp.MPolynomial], constant_columns: Sequence[Sequence[int]],
+              boundary: Boundary, rng: Callable[[int], bytes]) -> bytes:
+        ps = so.ProofStream()
+        state = self.step_begin(trace, boundary, rng)
+        boundary_quotients = state["boundary_quotients"]
+        n_fri = self.fri_domain_length
+        bq_codewords, bq_trees = [], []
+        for s in range(self.num_registers):                                         # :293-306
+            cw = coset_eval(boundary_quotients[s], n_fri, self.generator)
+            tree = oc.merkle_tree_fe(oc.from_ints(cw))
+            bq_codewords.append(cw)
+            bq_trees.append(tree)
+            ps.push(tree[-1].tobytes().hex())
+        self.step_transition(state, air, constant_columns, rng)
+        randomizer_codeword = coset_eval(state["randomizer_poly"], n_fri, self.generator)    # :356-360
+        randomizer_tree = oc.merkle_tree_fe(oc.from_ints(randomizer_codeword))
+        ps.push(randomizer_tree[-1].tobytes().hex())
+        combination = self.step_combine(state, air, boundary, ps.prover_fiat_shamir(32))
         combined_codeword = coset_eval(combination, n_fri, self.generator)          # :406
         indices = sorted(_fri_prove(self.fri, combined_codeword, ps))               # :409-410
         duplicated = sorted(indices + [(i + self.expansion_factor) % n_fri for i in indices])   # :415-419

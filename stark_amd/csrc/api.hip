@@ -953,22 +953,33 @@ extern "C" void stark_ctx_destroy(stark_ctx* ctx)
     delete ctx;
 }
 
+// Leaving a stream waits for what the context queued on it, except while either stream is being captured into a
+// graph: a synchronisation from the capturing thread is not allowed then, and the stream left holds no work of its
+// own that the capture could depend on if the caller bound and warmed up before capturing.
+static int32_t switch_stream(stark_ctx* ctx, hipStream_t next)
+{
+    if (next == ctx->stream) return STARK_OK;
+    hipStreamCaptureStatus from = hipStreamCaptureStatusNone, to = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(ctx->stream, &from);
+    (void)hipStreamIsCapturing(next, &to);
+    (void)hipGetLastError();
+    if (from == hipStreamCaptureStatusNone && to == hipStreamCaptureStatusNone) HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->stream = next;
+    return STARK_OK;
+}
+
 extern "C" int32_t stark_ctx_set_stream(stark_ctx* ctx, void* hip_stream)
 {
     CtxGuard guard_(ctx);
     if (!ctx) return fail(STARK_EARG, "null context");
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    ctx->stream = (hipStream_t)hip_stream;
-    return STARK_OK;
+    return switch_stream(ctx, (hipStream_t)hip_stream);
 }
 
 extern "C" int32_t stark_ctx_reset_stream(stark_ctx* ctx)
 {
     CtxGuard guard_(ctx);
     if (!ctx) return fail(STARK_EARG, "null context");
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    ctx->stream = ctx->own_stream;
-    return STARK_OK;
+    return switch_stream(ctx, ctx->own_stream);
 }
 
 extern "C" int32_t stark_ctx_synchronize(stark_ctx* ctx)

@@ -201,7 +201,23 @@ class Context:
             raise StarkError(rc, self.lib.stark_last_error().decode())
         self.h = h
         self.device = device
+        self._owned = True
+        self._stream = "own"                                     # the stream calls are queued on, as last set here
         self._handles: "weakref.WeakSet" = weakref.WeakSet()     # trees and layers that belong to this context
+
+    @classmethod
+    def wrap(cls, handle, device: int = 0) -> "Context":
+        """A Context over a stark_ctx* somebody else created and will destroy (the C++ mirror's process-wide
+        one, hostlib.lib.sh_context()): calls made here and calls the mirror makes share one stream and one
+        set of cached tables and blocks."""
+        self = cls.__new__(cls)
+        self.lib = _lib.load()
+        self.h = C.c_void_p(handle)
+        self.device = device
+        self._owned = False
+        self._stream = None                                      # unknown: the first set_stream always goes through
+        self._handles = weakref.WeakSet()
+        return self
 
     def _chk(self, rc: int):
         if rc:
@@ -216,7 +232,8 @@ class Context:
         if self.h:
             for handle in list(self._handles):
                 handle.free()
-            self.lib.stark_ctx_destroy(self.h)
+            if self._owned:
+                self.lib.stark_ctx_destroy(self.h)
             self.h = None
 
     def trim(self):
@@ -226,9 +243,20 @@ class Context:
     def set_stream(self, hip_stream: Optional[int]):
         """Launch on the caller's stream (None / 0 = HIP's default stream)."""
         self._chk(self.lib.stark_ctx_set_stream(self.h, hip_stream or None))
+        self._stream = int(hip_stream or 0)
+
+    def follow_stream(self, hip_stream: int):
+        """set_stream unless the context is already on that stream (what it was last pointed at through this
+        object; a context shared with other code is re-pointed every time)."""
+        if not self._owned or self._stream != int(hip_stream or 0):
+            self.set_stream(hip_stream)
 
     def reset_stream(self):
         self._chk(self.lib.stark_ctx_reset_stream(self.h))
+        self._stream = "own"
+
+    def copy_d2d(self, dst_ptr, src_ptr, nbytes: int):
+        self._chk(self.lib.stark_copy_d2d(self.h, _ptr(dst_ptr), _ptr(src_ptr), nbytes))
 
     def synchronize(self):
         self._chk(self.lib.stark_ctx_synchronize(self.h))
@@ -320,6 +348,10 @@ class Context:
                 ex[i * nv + v] = e[v] if v < len(e) else 0
         self._chk(self.lib.stark_mpoly_eval_dev(self.h, nv, ptrs, rot, k, w, ex,
                                                 None if mul_ptr is None else _ptr(mul_ptr), _ptr(out_ptr), n))
+
+    def poly_degree_post_dev(self, coeffs_ptr, n: int, result_ptr):
+        """poly_degree_dev without the wait: 0 for the zero polynomial, else degree + 1, as one uint64 at result_ptr."""
+        self._chk(self.lib.stark_poly_degree_post_dev(self.h, _ptr(coeffs_ptr), n, _ptr(result_ptr)))
 
     def poly_degree_dev(self, coeffs_ptr, n: int):
         """(degree, is_zero) of n coefficients, lowest first."""

@@ -34,20 +34,18 @@ class HipEngine:
 
     def __init__(self, ctx):
         self.ctx = ctx
-        self._bound = None
 
     def _bind(self, t: torch.Tensor) -> None:
         """The library launches on the context's stream; the tensors it is handed were produced by
         torch ops and collectives on torch's current stream, and its results are consumed there.
         Every engine call therefore first points the context at torch's current stream for the
         tensor's device (it may have changed under `with torch.cuda.stream(s)`), which orders the
-        two by plain stream order.  Switching synchronises the stream the context leaves."""
+        two by plain stream order.  Switching synchronises the stream the context leaves.  The
+        context itself remembers which stream it is on (Context.follow_stream), so a set_stream made
+        elsewhere on the same Context is seen here."""
         if not t.is_cuda:
             return
-        cur = torch.cuda.current_stream(t.device).cuda_stream
-        if cur != self._bound:
-            self.ctx.set_stream(cur)
-            self._bound = cur
+        self.ctx.follow_stream(torch.cuda.current_stream(t.device).cuda_stream)
 
     def ntt_batch(self, t: torch.Tensor, inverse: bool) -> None:
         self._bind(t)
@@ -77,6 +75,20 @@ class HipEngine:
         self._bind(recv)
         out = torch.empty((rows, world * run, 2), dtype=recv.dtype, device=recv.device)
         self.ctx.fourstep_unpack_dev(recv, world, rows, run, out)
+        return out
+
+    def compose_linear(self, t: torch.Tensor, s: int) -> None:
+        """Coefficient j (lowest first) of every column of t (cols, n, 2) times s^j, in place."""
+        self._bind(t)
+        cols, n, _ = t.shape
+        self.ctx.poly_compose_linear_dev(t, n, s, n_cols=cols, col_stride=n)
+
+    def transpose(self, t: torch.Tensor) -> torch.Tensor:
+        """(rows, cols, 2) -> (cols, rows, 2): the pack kernel with one destination."""
+        self._bind(t)
+        rows, cols, _ = t.shape
+        out = torch.empty((cols, rows, 2), dtype=t.dtype, device=t.device)
+        self.ctx.fourstep_pack_dev(t, rows, cols, 1, out)
         return out
 
     def coset_lde(self, coeffs: torch.Tensor, n_out: int, offset: int) -> torch.Tensor:
@@ -438,19 +450,19 @@ def _open_many(handle, indices: Sequence[int]) -> List[List[bytes]]:
     return [handle.open(i) for i in indices]
 
 
-def _sharded_openings(engine, commit: ShardedFriCommit, layer: int, positions: Sequence[int], rank: int, world: int,
-                      group):
-    """Values and authentication paths of `positions` in sharded layer `layer`, on every rank: the
-    owner of a position reads the element and the siblings inside its subtree; those travel in one
-    zero-padded all-reduce (non-owners contribute zeros); the upper siblings come from the
-    replicated top levels."""
-    c, period = commit.chunk_len, commit.period
+def open_in_shares(engine, share: torch.Tensor, forest, top, chunk_len: int, period: int, positions: Sequence[int],
+                   rank: int, world: int, group):
+    """Values and authentication paths (Merkle::open, merkle.rs:54-93) of `positions` of a vector dealt out in
+    chunks (fri_shard_of), on every rank: the owner of a position reads the element and the siblings inside
+    its subtree (`forest`); those travel in one zero-padded all-reduce (non-owners contribute zeros); the
+    upper siblings come from the replicated top levels (`top`)."""
+    c = chunk_len
     sub_levels = c.bit_length() - 1
     slot = 16 + 32 * sub_levels
     buf = torch.zeros((len(positions), slot), dtype=torch.uint8)
     mine = [(s, (i // period) * c + i % c) for s, i in enumerate(positions) if (i % period) // c == rank]
-    vals = engine.read_elements(commit.shares[layer], [l for _, l in mine])
-    subs = _open_many(commit.forests[layer], [l for _, l in mine])
+    vals = engine.read_elements(share, [l for _, l in mine])
+    subs = _open_many(forest, [l for _, l in mine])
     for (s, _), v, sub in zip(mine, vals, subs):
         raw = v.to_bytes(16, "little") + b"".join(sub)
         buf[s] = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
@@ -459,13 +471,19 @@ def _sharded_openings(engine, commit: ShardedFriCommit, layer: int, positions: S
         t = buf.to(torch.int32).to(dev)                  # byte sums of one owner and zeros: exact in any integer type
         dist.all_reduce(t, group=group)
         buf = t.cpu().to(torch.uint8)
-    uppers = _open_many(commit.tops[layer], [i // c for i in positions])
+    uppers = _open_many(top, [i // c for i in positions])
     out = []
     for s in range(len(positions)):
         raw = bytes(buf[s].tolist())
         value = int.from_bytes(raw[:16], "little")
         out.append((value, [raw[16 + 32 * j:48 + 32 * j] for j in range(sub_levels)] + uppers[s]))
     return out
+
+
+def _sharded_openings(engine, commit: ShardedFriCommit, layer: int, positions: Sequence[int], rank: int, world: int,
+                      group):
+    return open_in_shares(engine, commit.shares[layer], commit.forests[layer], commit.tops[layer], commit.chunk_len,
+                          commit.period, positions, rank, world, group)
 
 
 def fri_prove_sharded(engine, local: torch.Tensor, n: int, offset: int, omega: int, expansion_factor: int,

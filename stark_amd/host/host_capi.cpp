@@ -423,6 +423,7 @@ struct ChainJob {
     RescueChain chain;
     ScaledStark stark;
     std::vector<std::vector<FieldElement>> trace, constants;
+    std::vector<FieldElement> columns;               // the trace by columns (register s at s * rows), made on first use
     std::vector<MPolynomial> air;
     std::unique_ptr<DeviceVector> constant_polys;    // the statement's public polynomials, made once
     bool use_prepared = true;                        // off: prove and verify interpolate the constant columns themselves
@@ -430,6 +431,16 @@ struct ChainJob {
         : chain(rows), stark(expansion, ncol, security, chain.rp.m, rows), trace(chain.trace(input)),
           constants(chain.constant_columns()), air(chain.air()), constant_polys(stark.constant_polynomials(constants))
     {
+    }
+    ScaledStark::TraceColumns trace_columns()
+    {
+        const size_t rows = trace.size(), regs = chain.rp.m;
+        if (columns.empty()) {
+            columns.resize(rows * regs);
+            for (size_t c = 0; c < rows; c++)
+                for (size_t s = 0; s < regs; s++) columns[s * rows + c] = trace[c][s];
+        }
+        return ScaledStark::TraceColumns{columns.data(), rows};
     }
 };
 
@@ -458,6 +469,7 @@ void sh_chain_corrupt(void* h, size_t row, size_t reg)
 {
     ChainJob* j = (ChainJob*)h;
     j->trace.at(row).at(reg) = j->trace[row][reg] + FieldElement::one();
+    j->columns.clear();
 }
 void sh_chain_use_prepared_constants(void* h, int on) { ((ChainJob*)h)->use_prepared = on != 0; }
 size_t sh_chain_fri_domain_length(void* h) { return ((ChainJob*)h)->stark.fri_domain_length; }
@@ -489,6 +501,115 @@ int sh_chain_prove(void* h, const uint8_t* random, size_t n_random, uint8_t* pro
         }
         return (int)std::min<size_t>(used, 0x7fffffff);)
 }
+// the same through ScaledStark::prove_columns: the trace is handed over by columns (kept that way by the job)
+int sh_chain_prove_columns(void* h, const uint8_t* random, size_t n_random, uint8_t* proof_out, size_t* proof_len,
+                           double* timings)
+{
+    GUARD(
+        ChainJob* j = (ChainJob*)h;
+        size_t used = 0;
+        RandomSource rng = [&](uint8_t* dst, size_t n) {
+            if (used + n > n_random) throw Panic("random bytes exhausted");
+            std::memcpy(dst, random + used, n);
+            used += n;
+        };
+        ProveTimings tm;
+        std::vector<uint8_t> proof = j->stark.prove_columns(j->trace_columns(), j->air, j->constants,
+                                                            j->chain.boundary_constraints(j->trace.back()[0]), rng, &tm,
+                                                            j->use_prepared ? j->constant_polys.get() : nullptr);
+        if (proof_out) {
+            if (*proof_len < proof.size()) throw Panic("proof buffer too small");
+            std::memcpy(proof_out, proof.data(), proof.size());
+        }
+        *proof_len = proof.size();
+        if (timings) {
+            const double t[8] = {tm.host, tm.interpolate, tm.quotients, tm.lde, tm.merkle, tm.fri, tm.openings, tm.total};
+            std::memcpy(timings, t, sizeof t);
+        }
+        return (int)std::min<size_t>(used, 0x7fffffff);)
+}
+
+// ---- the steps of ScaledStark::prove one at a time, for a prover spread over several GPUs: every rank runs
+// them alike and does the FRI-domain work (extensions, commitments, FRI, openings) on its share
+struct ChainSession {
+    ChainJob* job;
+    const uint8_t* random;
+    size_t n_random, used = 0;
+    RandomSource rng;
+    ScaledStark::Run run;                            // destroyed first: joins the helper thread that reads `rng`
+    ChainSession(ChainJob* j, const uint8_t* r, size_t n) : job(j), random(r), n_random(n)
+    {
+        rng = [this](uint8_t* dst, size_t k) {
+            if (used + k > n_random) throw Panic("random bytes exhausted");
+            std::memcpy(dst, random + used, k);
+            used += k;
+        };
+    }
+};
+// `random` must stay valid until sh_session_free
+void* sh_session_begin(void* h, const uint8_t* random, size_t n_random)
+{
+    ChainSession* s = nullptr;
+    try {
+        ChainJob* j = (ChainJob*)h;
+        s = new ChainSession(j, random, n_random);
+        j->stark.begin(s->run, j->trace_columns(), j->air, j->constants.size(),
+                       j->chain.boundary_constraints(j->trace.back()[0]), s->rng,
+                       j->use_prepared ? j->constant_polys.get() : nullptr);
+        return s;
+    } catch (const std::exception& e) {
+        g_panic = e.what();
+        delete s;
+        return nullptr;
+    }
+}
+void sh_session_free(void* v) { delete (ChainSession*)v; }
+// out: registers, boundary-quotient coefficients per register, their column stride, randomizer / combination
+// coefficients, FRI domain length, expansion factor, colinearity tests
+void sh_session_shape(void* v, uint64_t out[8])
+{
+    ChainSession* s = (ChainSession*)v;
+    const ScaledStark& st = s->job->stark;
+    const uint64_t vals[8] = {s->run.R, s->run.n_rows, s->run.n_b, s->run.max_deg + 1, st.fri_domain_length,
+                              st.expansion_factor, st.num_colinearity_tests, 0};
+    std::memcpy(out, vals, sizeof vals);
+}
+// device pointers of the step results: 0 boundary quotients, 1 randomizer, 2 combination (NULL before their step)
+const void* sh_session_coefficients(void* v, int which)
+{
+    ChainSession* s = (ChainSession*)v;
+    const DeviceVector* d = which == 0 ? s->run.bq.get() : which == 1 ? s->run.randomizer.get() : s->run.combination.get();
+    return d ? d->words() : nullptr;
+}
+int sh_session_transition(void* v)
+{
+    GUARD(
+        ChainSession* s = (ChainSession*)v;
+        s->job->stark.transition_quotients(s->run, s->job->air, s->job->constants);
+        s->job->stark.randomizer_polynomial(s->run);
+        return 0;)
+}
+int sh_session_combine(void* v, const uint8_t* challenge, size_t len)
+{
+    GUARD(
+        ChainSession* s = (ChainSession*)v;
+        s->job->stark.combine(s->run, std::vector<uint8_t>(challenge, challenge + len));
+        return 0;)
+}
+// the degree assertions of the steps; timings as sh_chain_prove gives them (the caller's own laps not included)
+int sh_session_finish(void* v, double* timings)
+{
+    GUARD(
+        ChainSession* s = (ChainSession*)v;
+        s->job->stark.check_degrees(s->run);
+        if (timings) {
+            const ProveTimings& tm = s->run.tm;
+            const double t[8] = {tm.host, tm.interpolate, tm.quotients, tm.lde, tm.merkle, tm.fri, tm.openings, tm.total};
+            std::memcpy(timings, t, sizeof t);
+        }
+        return 0;)
+}
+
 // 1 accept / 0 reject / -1 panic
 int sh_chain_verify(void* h, const uint64_t* output, const uint8_t* proof, size_t proof_len)
 {

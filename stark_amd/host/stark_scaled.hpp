@@ -30,6 +30,7 @@
 #include <atomic>
 #include <chrono>
 #include <future>
+#include <mutex>
 #include <thread>
 
 #include "stark_prover.hpp"
@@ -196,6 +197,7 @@ struct ScaledStark {
     mutable std::unique_ptr<DeviceVector> tz_coeffs;
     mutable std::vector<uint8_t> random_staging;
     mutable std::vector<FieldElement> column_staging;         // the trace by columns, on its way to the device
+    mutable std::mutex staging_mu;
 
     // stark.rs:34-86 without the assertion on omicron's value (:65) and without the table of
     // omicron's powers (:63), which only the zeroifier needed
@@ -340,95 +342,142 @@ struct ScaledStark {
         return t;
     }
 
-    // Stark::prove (:223-471).  trace[c][s] is register s at cycle c; constant_columns[k][c] is constant k of
-    // the transition from cycle c to c + 1; the AIR's variables are [x, registers at c, registers at c + 1,
-    // constants].  `rng` is read as ONE byte stream in the reference's drawing order: 17 bytes per randomizer
-    // value row by row (:237-253), then 17 bytes per randomizer coefficient, highest degree first (:344-353).
-    // `prepared`, if given, is constant_polynomials(constant_columns) made beforehand: the columns are public
-    // parameters of the statement (the reference receives the round-constant polynomials inside its
-    // transition constraints, made by rescue_prime.rs:309-359 before Stark::prove is called).
-    std::vector<uint8_t> prove(const std::vector<std::vector<FieldElement>>& trace, const std::vector<MPolynomial>& air,
-                               const std::vector<std::vector<FieldElement>>& constant_columns,
-                               const std::vector<BoundaryCondition>& boundary, const RandomSource& rng,
-                               ProveTimings* timings = nullptr, const DeviceVector* prepared = nullptr) const
-    {
+    // ------------------------------------------------------------------------------------------------
+    // Stark::prove (:223-471) as the steps it is made of.  What the steps hand to one another lives on the
+    // device in a Run.  prove() runs them on one GPU; a prover spread over several GPUs runs the same steps on
+    // every rank and only does differently what happens on the FRI domain (low-degree extensions, commitments,
+    // FRI, openings), which is why those are not in the steps.
+    // ------------------------------------------------------------------------------------------------
+    // The trace by columns: register s at cycle c is host[s * stride + c].
+    struct TraceColumns {
+        const FieldElement* host = nullptr;
+        size_t stride = 0;
+    };
+    struct Run {
         typedef std::chrono::steady_clock Clock;
-        stark_ctx* ctx = context();
+        std::unique_lock<std::mutex> busy;                  // one proof at a time per ScaledStark (the caches below)
         ProveTimings tm;
-        const auto t_begin = Clock::now();
-        auto mark = Clock::now();
-        auto lap = [&](double& slot) {                       // device work is asynchronous: settle it, then charge the lap
-            check(stark_ctx_synchronize(ctx));
+        Clock::time_point t_begin, mark;
+        size_t R = 0, T = 0, n_rows = 0, n_b = 0, n_q = 0, K = 0, n_vars = 0, max_deg = 0, n_random = 0, n_air = 0;
+        std::unique_ptr<DeviceVector> tp, bq, tq, randomizer, combination, made, posted;
+        std::unique_ptr<DeviceBuffer> raw_random;
+        const DeviceVector* constants = nullptr;
+        std::vector<size_t> bq_bounds, tq_bounds;
+        std::future<void> drawn;
+        Run() = default;
+        Run(const Run&) = delete;
+        ~Run()
+        {
+            if (drawn.valid()) drawn.wait();                // the helper thread writes into this Run's buffers
+        }
+        void lap(double& slot)                              // device work is asynchronous: settle it, then charge the lap
+        {
+            check(stark_ctx_synchronize(context()));
             const auto now = Clock::now();
             slot += std::chrono::duration<double, std::milli>(now - mark).count();
             mark = now;
-        };
-        if (trace.size() != original_trace_length) throw Panic("trace length differs from the one this Stark was made for");
-        const size_t R = num_registers, T = original_trace_length, n_rows = T + num_randomizers;
-        const size_t n_o = omicron_domain_length, n_fri = fri_domain_length, K = constant_columns.size();
-        const size_t n_vars = 1 + 2 * R + K;
-        if (n_vars > 16) throw Panic("at most 16 variables in a constraint");
+        }
+        // what the random source threw on the helper thread, if anything, as the failure to report
+        void surface_draw_error()
+        {
+            if (!drawn.valid()) return;
+            try {
+                drawn.get();
+            } catch (const std::exception& e) {
+                throw Panic(e.what());
+            }
+        }
+    };
+    mutable std::mutex prove_mu;
+
+    // a second context on the same GPU: the random bytes go up through it (its own stream and staging lanes)
+    // while the proof's kernels run on the first
+    static stark_ctx* upload_context()
+    {
+        static stark_ctx* ctx = [] {
+            stark_ctx* c = nullptr;
+            int dev = 0;
+            const char* e = std::getenv("STARK_DEVICE");
+            if (!e || !*e) e = std::getenv("LOCAL_RANK");
+            if (e && *e) dev = std::atoi(e);
+            check(stark_ctx_create(dev, &c));
+            return c;
+        }();
+        return ctx;
+    }
+
+    // :237-288: randomizer rows, trace polynomials, boundary quotients (coefficients in run.bq, column s at
+    // s * run.n_b).  `rng` is read as ONE byte stream in the reference's drawing order: 17 bytes per randomizer
+    // value row by row (:237-253), then 17 bytes per randomizer coefficient, highest degree first (:344-353); the
+    // second part is drawn and sent to the device on a helper thread while the device works, so `rng` and
+    // `run` must stay alive until randomizer_polynomial() or the Run's destructor has joined it.
+    void begin(Run& run, const TraceColumns& trace, const std::vector<MPolynomial>& air, size_t n_constant_columns,
+               const std::vector<BoundaryCondition>& boundary, const RandomSource& rng,
+               const DeviceVector* prepared_constants) const
+    {
+        stark_ctx* ctx = context();
+        run.busy = std::unique_lock<std::mutex>(prove_mu);
+        run.t_begin = run.mark = Run::Clock::now();
+        const size_t R = run.R = num_registers, T = run.T = original_trace_length;
+        const size_t n_rows = run.n_rows = T + num_randomizers;
+        run.K = n_constant_columns;
+        run.n_vars = 1 + 2 * R + run.K;
+        run.n_air = air.size();
+        if (run.n_vars > 16) throw Panic("at most 16 variables in a constraint");
+        if (!trace.host || trace.stride < T) throw Panic("trace columns shorter than the trace");
         uint64_t gen_w[2];
         fe_words(generator, gen_w);
-        ProofStream ps;
 
-        // ---- trace columns with their randomizers (:237-253), interpolated (:260-275)
-        // (the staging vector is kept from proof to proof: a fresh one costs a page fault per 4 KiB written and
-        // a slower first transfer, together more than the copy itself at 2^20 rows)
-        if (column_staging.size() != R * n_rows) column_staging.assign(R * n_rows, FieldElement::zero());
-        std::vector<FieldElement>& columns = column_staging;
-        {
-            // rows to columns: every row is a heap object of its own, so this is a walk through memory;
-            // a few threads take a range of cycles each
-            const size_t workers = T >= ((size_t)1 << 16) ? 8 : 1;
-            std::vector<std::thread> pool;
-            std::vector<int> bad(workers, 0);
-            for (size_t w = 0; w < workers; w++)
-                pool.emplace_back([&, w] {
-                    for (size_t c = T * w / workers; c < T * (w + 1) / workers; c++) {
-                        if (trace[c].size() != R) {
-                            bad[w] = 1;
-                            return;
-                        }
-                        for (size_t s = 0; s < R; s++) columns[s * n_rows + c] = trace[c][s];
-                    }
-                });
-            for (auto& th : pool) th.join();
-            for (int b : bad)
-                if (b) throw Panic("trace row has the wrong number of registers");
-        }
+        // ---- trace columns with their randomizers (:237-253)
+        run.tp.reset(new DeviceVector(R * n_rows));
+        DeviceVector trace_values(R * n_rows);
         {
             std::vector<uint8_t> bytes(17 * num_randomizers * R);
             rng(bytes.data(), bytes.size());
-            for (size_t k = 0; k < num_randomizers; k++)
-                for (size_t s = 0; s < R; s++) {
+            std::vector<FieldElement> tail(num_randomizers);
+            for (size_t s = 0; s < R; s++) {
+                check(stark_copy_h2d(ctx, trace_values.words(s * n_rows), trace.host + s * trace.stride, T * 16));
+                for (size_t k = 0; k < num_randomizers; k++) {
                     const uint8_t* b = bytes.data() + 17 * (k * R + s);
-                    columns[s * n_rows + T + k] = FieldElement::sample(std::vector<uint8_t>(b, b + 17));
+                    tail[k] = FieldElement::sample(std::vector<uint8_t>(b, b + 17));
                 }
+                trace_values.upload(tail, s * n_rows + T);
+            }
         }
-        DeviceVector trace_values(R * n_rows), tp(R * n_rows);
-        trace_values.upload(columns);
-        // the randomizer polynomial's raw bytes (:344-353) are the next thing the random source yields: they are
-        // drawn on a helper thread while the device works on the trace (tens of megabytes for a long trace).  The
-        // draw starts after the trace has gone up: side by side the two copies fight for the memory system and
-        // the upload takes 7 ms instead of 1.
-        const size_t max_deg = max_degree(air);
-        const size_t n_random = 17 * (max_deg + 1);
-        if (random_staging.size() < n_random) random_staging.resize(n_random);
-        std::future<void> drawn = std::async(std::launch::async, [&] { rng(random_staging.data(), n_random); });
-        lap(tm.host);
-        geo.interpolate(trace_values.words(), n_rows, R, n_rows, tp.words(), n_rows);
-        std::unique_ptr<DeviceVector> made;
-        if (!prepared) made = constant_polynomials(constant_columns);
-        const DeviceVector* constants = prepared ? prepared : made.get();
-        if (constants->count < std::max<size_t>(1, constant_columns.size() * (T - 1)))
-            throw Panic("prepared constant polynomials do not match the constant columns");
-        lap(tm.interpolate);
+        // the randomizer polynomial's raw bytes (:344-353) are the next thing the random source yields: tens of
+        // megabytes for a long trace, drawn and uploaded (through a context of its own) on a helper thread while
+        // the device works on the trace.  The helper starts after the trace has gone up: side by side the two
+        // copies fight for the host's memory system and the trace upload takes 7 ms instead of 1.
+        run.max_deg = max_degree(air);
+        run.n_random = 17 * (run.max_deg + 1);
+        if (random_staging.size() < run.n_random) random_staging.resize(run.n_random);
+        run.raw_random.reset(new DeviceBuffer(run.n_random));
+        {
+            uint8_t* staging = random_staging.data();
+            void* dst = run.raw_random->p;
+            const size_t n_random = run.n_random;
+            const RandomSource* source = &rng;
+            run.drawn = std::async(std::launch::async, [staging, dst, n_random, source] {
+                (*source)(staging, n_random);
+                check(stark_copy_h2d(upload_context(), dst, staging, n_random));
+            });
+        }
+        run.lap(run.tm.host);
+        // ---- interpolation (:260-275)
+        geo.interpolate(trace_values.words(), n_rows, R, n_rows, run.tp->words(), n_rows);
+        if (prepared_constants) {
+            run.constants = prepared_constants;
+            if (run.constants->count < std::max<size_t>(1, run.K * (T - 1)))
+                throw Panic("prepared constant polynomials do not match the constant columns");
+        }
+        run.lap(run.tm.interpolate);
 
         // ---- boundary quotients (:277-288): (trace polynomial - interpolant) / zeroifier on a coset
         std::vector<Polynomial> interpolants = boundary_interpolants(boundary), zeroifiers = boundary_zeroifiers(boundary);
-        const size_t n_b = next_pow2(n_rows);
-        DeviceVector bq(R * n_b);                              // quotient coefficients, column s at s * n_b
+        const size_t n_b = run.n_b = next_pow2(n_rows);
+        run.bq.reset(new DeviceVector(R * n_b));           // quotient coefficients, column s at s * n_b
+        run.posted.reset(new DeviceVector(R + air.size())); // the degrees, read once at the end (one word each)
+        DeviceVector& bq = *run.bq;
         {
             DeviceVector small(R * 2 * 8), den(R * n_b);
             for (size_t s = 0; s < R; s++) {
@@ -438,7 +487,7 @@ struct ScaledStark {
                 std::vector<FieldElement> lo_z(zeroifiers[s].coeffs.rbegin(), zeroifiers[s].coeffs.rend());
                 small.upload(lo_i, s * 16);
                 small.upload(lo_z, s * 16 + 8);
-                const uint64_t* srcs[2] = {tp.words(s * n_rows), small.words(s * 16)};
+                const uint64_t* srcs[2] = {run.tp->words(s * n_rows), small.words(s * 16)};
                 const size_t lens[2] = {n_rows, lo_i.size()}, shifts[2] = {0, 0};
                 uint64_t weights[4] = {1, 0, 0, 0};
                 fe_words(-FieldElement::one(), weights + 2);
@@ -451,44 +500,43 @@ struct ScaledStark {
             check(stark_vec_inv_dev(ctx, den.words(), den.words(), R * n_b));
             check(stark_vec_mul_dev(ctx, num.words(), den.words(), bq.words(), R * n_b));
             check(stark_coset_interpolate_batch_dev(ctx, bq.words(), n_b, R, n_b, gen_w));
-            check(stark_ctx_synchronize(ctx));
+            for (size_t s = 0; s < R; s++)
+                check(stark_poly_degree_post_dev(ctx, bq.words(s * n_b), n_b, run.posted->words(s)));
+            check(stark_ctx_synchronize(ctx));                // the work buffers go out of scope
         }
-        std::vector<size_t> bq_bounds = boundary_quotient_degree_bounds(n_rows, boundary);
-        for (size_t s = 0; s < R; s++) {
-            size_t deg = 0;
-            check(stark_poly_degree_dev(ctx, bq.words(s * n_b), n_b, &deg, nullptr));
-            if (deg > bq_bounds[s]) throw Panic("the trace does not meet its boundary conditions");
-        }
-        lap(tm.quotients);
+        run.bq_bounds = boundary_quotient_degree_bounds(n_rows, boundary);
+        run.tq_bounds = transition_quotient_degree_bounds(air);
+        run.lap(run.tm.quotients);
+    }
 
-        // ---- commit to the boundary quotients on the FRI domain (:291-306)
-        DeviceVector bq_codewords(R * n_fri);
-        check(stark_coset_lde_batch_dev(ctx, bq.words(), n_rows, n_b, R, n_fri, gen_w, bq_codewords.words(), n_fri));
-        lap(tm.lde);
-        std::vector<std::unique_ptr<TreeHandle>> bq_trees;
-        for (size_t s = 0; s < R; s++) {
-            bq_trees.emplace_back(new TreeHandle());
-            HashOutput root;
-            check(stark_merkle_commit_fe_dev(ctx, bq_codewords.words(s * n_fri), n_fri, root.data(), &bq_trees.back()->t));
-            ps.push(wire::hex_encode(root.data(), 32));
+    // :309-341: transition quotients by values on a coset of a subgroup that contains omicron; the composition
+    // with omicron * x (:319-325) is the same column read omicron's place count further on.  Coefficients in
+    // run.tq, constraint a at a * run.n_q.
+    void transition_quotients(Run& run, const std::vector<MPolynomial>& air,
+                              const std::vector<std::vector<FieldElement>>& constant_columns) const
+    {
+        stark_ctx* ctx = context();
+        const size_t R = run.R, T = run.T, n_rows = run.n_rows, K = run.K, n_vars = run.n_vars, n_o = omicron_domain_length;
+        uint64_t gen_w[2];
+        fe_words(generator, gen_w);
+        if (!run.constants) {
+            run.made = constant_polynomials(constant_columns);
+            run.constants = run.made.get();
+            run.lap(run.tm.interpolate);
         }
-        lap(tm.merkle);
-
-        // ---- transition quotients (:309-341) by values on a coset of a subgroup that contains omicron: the
-        // composition with omicron * x (:319-325) is the same column read omicron's place count further on
-        std::vector<size_t> tq_bounds = transition_quotient_degree_bounds(air);
         // the quotients have max_deg + 1 coefficients at most; their values are taken on a coset of that many
         // points (the omicron domain's size in the reference's own configuration), never fewer than the
         // omicron domain so that multiplying x by omicron stays a whole number of places
-        const size_t n_q = std::max(n_o, max_deg + 1), omicron_places = n_q / n_o;
-        DeviceVector tq(air.size() * n_q);                     // quotient coefficients, constraint a at a * n_q
+        const size_t n_q = run.n_q = std::max(n_o, run.max_deg + 1), omicron_places = n_q / n_o;
+        run.tq.reset(new DeviceVector(air.size() * n_q));
+        DeviceVector& tq = *run.tq;
         {
             DeviceVector cols(n_vars * n_q), tz_values(n_q), x_poly(2);
             x_poly.upload({FieldElement::zero(), FieldElement::one()});
             check(stark_coset_lde_batch_dev(ctx, x_poly.words(), 2, 2, 1, n_q, gen_w, cols.words(0), n_q));
-            check(stark_coset_lde_batch_dev(ctx, tp.words(), n_rows, n_rows, R, n_q, gen_w, cols.words(n_q), n_q));
+            check(stark_coset_lde_batch_dev(ctx, run.tp->words(), n_rows, n_rows, R, n_q, gen_w, cols.words(n_q), n_q));
             if (K)
-                check(stark_coset_lde_batch_dev(ctx, constants->words(), T - 1, T - 1, K, n_q, gen_w,
+                check(stark_coset_lde_batch_dev(ctx, run.constants->words(), T - 1, T - 1, K, n_q, gen_w,
                                                 cols.words((1 + R) * n_q), n_q));
             if (!tz_coeffs) {
                 tz_coeffs.reset(new DeviceVector(T));
@@ -496,7 +544,7 @@ struct ScaledStark {
             }
             check(stark_coset_lde_batch_dev(ctx, tz_coeffs->words(), T, T, 1, n_q, gen_w, tz_values.words(), n_q));
             check(stark_vec_inv_dev(ctx, tz_values.words(), tz_values.words(), n_q));
-            // variables: x, registers now, registers one step on (rotation 1), constants
+            // variables: x, registers now, registers one step on (rotation), constants
             std::vector<const uint64_t*> ptrs(n_vars);
             std::vector<size_t> rot(n_vars, 0);
             ptrs[0] = cols.words(0);
@@ -512,90 +560,201 @@ struct ScaledStark {
                                            tt.exps.data(), tz_values.words(), tq.words(a * n_q), n_q));
             }
             check(stark_coset_interpolate_batch_dev(ctx, tq.words(), n_q, air.size(), n_q, gen_w));
+            for (size_t a = 0; a < air.size(); a++)            // :379-380, read with the other degrees at the end
+                check(stark_poly_degree_post_dev(ctx, tq.words(a * n_q), n_q, run.posted->words(R + a)));
             check(stark_ctx_synchronize(ctx));
         }
-        for (size_t a = 0; a < air.size(); a++) {              // :379-380
-            size_t deg = 0;
-            check(stark_poly_degree_dev(ctx, tq.words(a * n_q), n_q, &deg, nullptr));
-            if (deg != tq_bounds[a])
-                throw Panic("assertion failed: tq_degrees == self.transition_quotient_degree_bounds(transition_constraints.clone())");
-        }
-        lap(tm.quotients);
+        run.lap(run.tm.quotients);
+    }
 
-        // ---- randomizer polynomial (:344-360)
-        DeviceVector randomizer(max_deg + 1), rz_codeword(n_fri);
-        {
-            drawn.get();                                          // rethrows what the random source threw
-            DeviceBuffer raw(n_random);
-            check(stark_copy_h2d(ctx, raw.p, random_staging.data(), n_random));
-            check(stark_sample_bytes_dev(ctx, (const uint8_t*)raw.p, 17, max_deg + 1, 1, randomizer.words()));
-            check(stark_ctx_synchronize(ctx));
+    // :344-353: the randomizer polynomial's coefficients (lowest first) in run.randomizer
+    void randomizer_polynomial(Run& run) const
+    {
+        stark_ctx* ctx = context();
+        run.randomizer.reset(new DeviceVector(run.max_deg + 1));
+        run.drawn.get();                                      // rethrows what the random source threw
+        check(stark_sample_bytes_dev(ctx, (const uint8_t*)run.raw_random->p, 17, run.max_deg + 1, 1, run.randomizer->words()));
+        run.lap(run.tm.host);
+    }
+
+    // :372-404: the weights from the transcript's challenge and the weighted sum, coefficients in run.combination
+    void combine(Run& run, const std::vector<uint8_t>& challenge) const
+    {
+        stark_ctx* ctx = context();
+        const size_t R = run.R, n_air = run.n_air, max_deg = run.max_deg;
+        std::vector<FieldElement> weights = sample_weights(1 + 2 * n_air + 2 * R, challenge);
+        run.combination.reset(new DeviceVector(max_deg + 1));
+        DeviceVector& combination = *run.combination;
+        std::vector<const uint64_t*> srcs;
+        std::vector<size_t> lens, shifts;
+        auto term = [&](const uint64_t* p, size_t len, size_t shift) {
+            srcs.push_back(p);
+            lens.push_back(len);
+            shifts.push_back(shift);
+        };
+        term(run.randomizer->words(), max_deg + 1, 0);
+        for (size_t a = 0; a < n_air; a++) {
+            term(run.tq->words(a * run.n_q), run.tq_bounds[a] + 1, 0);
+            term(run.tq->words(a * run.n_q), run.tq_bounds[a] + 1, max_deg - run.tq_bounds[a]);
         }
-        lap(tm.host);
-        check(stark_coset_lde_batch_dev(ctx, randomizer.words(), max_deg + 1, max_deg + 1, 1, n_fri, gen_w,
+        for (size_t s = 0; s < R; s++) {
+            term(run.bq->words(s * run.n_b), run.bq_bounds[s] + 1, 0);
+            term(run.bq->words(s * run.n_b), run.bq_bounds[s] + 1, max_deg - run.bq_bounds[s]);
+        }
+        std::vector<uint64_t> w(2 * weights.size());
+        for (size_t i = 0; i < weights.size(); i++) fe_words(weights[i], &w[2 * i]);
+        // at most 16 terms per pass: the first pass writes, later passes add to what is there
+        for (size_t at = 0; at < srcs.size();) {
+            std::vector<const uint64_t*> s2;
+            std::vector<size_t> l2, h2;
+            std::vector<uint64_t> w2;
+            if (at) {
+                s2.push_back(combination.words());
+                l2.push_back(max_deg + 1);
+                h2.push_back(0);
+                w2.push_back(1);
+                w2.push_back(0);
+            }
+            while (at < srcs.size() && s2.size() < 16) {
+                s2.push_back(srcs[at]);
+                l2.push_back(lens[at]);
+                h2.push_back(shifts[at]);
+                w2.push_back(w[2 * at]);
+                w2.push_back(w[2 * at + 1]);
+                at++;
+            }
+            check(stark_poly_lincomb_dev(ctx, s2.size(), s2.data(), l2.data(), h2.data(), w2.data(), combination.words(),
+                                         max_deg + 1));
+        }
+        run.lap(run.tm.quotients);
+    }
+
+    // the degree assertions of the steps above (:379-380 and the exactness of the boundary division), from the
+    // words the steps posted on the device: one read
+    void check_degrees(Run& run) const
+    {
+        std::vector<FieldElement> words = run.posted->download(0, run.R + run.n_air);
+        auto degree = [&](size_t i) {
+            const uint64_t r = (uint64_t)words[i].value;
+            return r ? (size_t)(r - 1) : (size_t)0;             // univariate_poly.rs:69-85: the zero polynomial has degree 0
+        };
+        for (size_t s = 0; s < run.R; s++)
+            if (degree(s) > run.bq_bounds[s]) throw Panic("the trace does not meet its boundary conditions");
+        for (size_t a = 0; a < run.n_air; a++)
+            if (degree(run.R + a) != run.tq_bounds[a])
+                throw Panic("assertion failed: tq_degrees == self.transition_quotient_degree_bounds(transition_constraints.clone())");
+    }
+
+    // Stark::prove (:223-471).  trace[c][s] is register s at cycle c; constant_columns[k][c] is constant k of
+    // the transition from cycle c to c + 1; the AIR's variables are [x, registers at c, registers at c + 1,
+    // constants].  `prepared`, if given, is constant_polynomials(constant_columns) made beforehand: the columns
+    // are public parameters of the statement (the reference receives the round-constant polynomials inside its
+    // transition constraints, made by rescue_prime.rs:309-359 before Stark::prove is called).
+    // One proof at a time per ScaledStark object (a second caller waits).
+    std::vector<uint8_t> prove(const std::vector<std::vector<FieldElement>>& trace, const std::vector<MPolynomial>& air,
+                               const std::vector<std::vector<FieldElement>>& constant_columns,
+                               const std::vector<BoundaryCondition>& boundary, const RandomSource& rng,
+                               ProveTimings* timings = nullptr, const DeviceVector* prepared = nullptr) const
+    {
+        const auto t0 = std::chrono::steady_clock::now();
+        if (trace.size() != original_trace_length) throw Panic("trace length differs from the one this Stark was made for");
+        const size_t R = num_registers, T = original_trace_length;
+        // rows to columns: every row is a heap object of its own, so this is a walk through memory; a few threads
+        // take a range of cycles each.  (The staging vector is kept from proof to proof: a fresh one costs a page
+        // fault per 4 KiB written, more than the copy itself at 2^20 rows.)
+        std::unique_lock<std::mutex> staging(staging_mu);
+        if (column_staging.size() != R * T) column_staging.assign(R * T, FieldElement::zero());
+        {
+            const size_t workers = T >= ((size_t)1 << 16) ? 8 : 1;
+            std::vector<std::thread> pool;
+            std::vector<int> bad(workers, 0);
+            for (size_t w = 0; w < workers; w++)
+                pool.emplace_back([&, w] {
+                    for (size_t c = T * w / workers; c < T * (w + 1) / workers; c++) {
+                        if (trace[c].size() != R) {
+                            bad[w] = 1;
+                            return;
+                        }
+                        for (size_t s = 0; s < R; s++) column_staging[s * T + c] = trace[c][s];
+                    }
+                });
+            for (auto& th : pool) th.join();
+            for (int b : bad)
+                if (b) throw Panic("trace row has the wrong number of registers");
+        }
+        const double transposed = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        std::vector<uint8_t> proof =
+            prove_columns(TraceColumns{column_staging.data(), T}, air, constant_columns, boundary, rng, timings, prepared);
+        if (timings) {
+            timings->host += transposed;
+            timings->total += transposed;
+        }
+        return proof;
+    }
+
+    // The same with the trace handed over by columns (no transposition, no staging copy).
+    std::vector<uint8_t> prove_columns(const TraceColumns& trace, const std::vector<MPolynomial>& air,
+                                       const std::vector<std::vector<FieldElement>>& constant_columns,
+                                       const std::vector<BoundaryCondition>& boundary, const RandomSource& rng,
+                                       ProveTimings* timings = nullptr, const DeviceVector* prepared = nullptr) const
+    {
+        Run run;
+        try {
+            return prove_steps(run, trace, air, constant_columns, boundary, rng, timings, prepared);
+        } catch (...) {
+            run.surface_draw_error();                         // a failure of the random source is the one to report
+            throw;
+        }
+    }
+
+    std::vector<uint8_t> prove_steps(Run& run, const TraceColumns& trace, const std::vector<MPolynomial>& air,
+                                     const std::vector<std::vector<FieldElement>>& constant_columns,
+                                     const std::vector<BoundaryCondition>& boundary, const RandomSource& rng,
+                                     ProveTimings* timings, const DeviceVector* prepared) const
+    {
+        stark_ctx* ctx = context();
+        const size_t R = num_registers, n_fri = fri_domain_length;
+        uint64_t gen_w[2];
+        fe_words(generator, gen_w);
+        ProofStream ps;
+        begin(run, trace, air, constant_columns.size(), boundary, rng, prepared);
+
+        // ---- commit to the boundary quotients on the FRI domain (:291-306)
+        DeviceVector bq_codewords(R * n_fri);
+        check(stark_coset_lde_batch_dev(ctx, run.bq->words(), run.n_rows, run.n_b, R, n_fri, gen_w, bq_codewords.words(), n_fri));
+        run.lap(run.tm.lde);
+        std::vector<std::unique_ptr<TreeHandle>> bq_trees;
+        for (size_t s = 0; s < R; s++) {
+            bq_trees.emplace_back(new TreeHandle());
+            HashOutput root;
+            check(stark_merkle_commit_fe_dev(ctx, bq_codewords.words(s * n_fri), n_fri, root.data(), &bq_trees.back()->t));
+            ps.push(wire::hex_encode(root.data(), 32));
+        }
+        run.lap(run.tm.merkle);
+
+        transition_quotients(run, air, constant_columns);
+        randomizer_polynomial(run);
+        // ---- the randomizer's codeword and commitment (:356-360)
+        DeviceVector rz_codeword(n_fri);
+        check(stark_coset_lde_batch_dev(ctx, run.randomizer->words(), run.max_deg + 1, run.max_deg + 1, 1, n_fri, gen_w,
                                         rz_codeword.words(), n_fri));
-        lap(tm.lde);
+        run.lap(run.tm.lde);
         TreeHandle rz_tree;
         {
             HashOutput root;
             check(stark_merkle_commit_fe_dev(ctx, rz_codeword.words(), n_fri, root.data(), &rz_tree.t));
             ps.push(wire::hex_encode(root.data(), 32));
         }
-        lap(tm.merkle);
+        run.lap(run.tm.merkle);
 
-        // ---- nonlinear combination (:372-404): one pass over the coefficient vectors
-        std::vector<FieldElement> weights = sample_weights(1 + 2 * air.size() + 2 * R, ps.prover_fiat_shamir(32));
-        DeviceVector combination(max_deg + 1), comb_codeword(n_fri);
-        {
-            std::vector<const uint64_t*> srcs;
-            std::vector<size_t> lens, shifts;
-            auto term = [&](const uint64_t* p, size_t len, size_t shift) {
-                srcs.push_back(p);
-                lens.push_back(len);
-                shifts.push_back(shift);
-            };
-            term(randomizer.words(), max_deg + 1, 0);
-            for (size_t a = 0; a < air.size(); a++) {
-                term(tq.words(a * n_q), tq_bounds[a] + 1, 0);
-                term(tq.words(a * n_q), tq_bounds[a] + 1, max_deg - tq_bounds[a]);
-            }
-            for (size_t s = 0; s < R; s++) {
-                term(bq.words(s * n_b), bq_bounds[s] + 1, 0);
-                term(bq.words(s * n_b), bq_bounds[s] + 1, max_deg - bq_bounds[s]);
-            }
-            std::vector<uint64_t> w(2 * weights.size());
-            for (size_t i = 0; i < weights.size(); i++) fe_words(weights[i], &w[2 * i]);
-            // at most 16 terms per pass: the first pass writes, later passes add to what is there
-            for (size_t at = 0; at < srcs.size();) {
-                std::vector<const uint64_t*> s2;
-                std::vector<size_t> l2, h2;
-                std::vector<uint64_t> w2;
-                if (at) {
-                    s2.push_back(combination.words());
-                    l2.push_back(max_deg + 1);
-                    h2.push_back(0);
-                    w2.push_back(1);
-                    w2.push_back(0);
-                }
-                while (at < srcs.size() && s2.size() < 16) {
-                    s2.push_back(srcs[at]);
-                    l2.push_back(lens[at]);
-                    h2.push_back(shifts[at]);
-                    w2.push_back(w[2 * at]);
-                    w2.push_back(w[2 * at + 1]);
-                    at++;
-                }
-                check(stark_poly_lincomb_dev(ctx, s2.size(), s2.data(), l2.data(), h2.data(), w2.data(),
-                                             combination.words(), max_deg + 1));
-            }
-        }
-        lap(tm.quotients);
-        check(stark_coset_lde_batch_dev(ctx, combination.words(), max_deg + 1, max_deg + 1, 1, n_fri, gen_w,
+        combine(run, ps.prover_fiat_shamir(32));
+        DeviceVector comb_codeword(n_fri);
+        check(stark_coset_lde_batch_dev(ctx, run.combination->words(), run.max_deg + 1, run.max_deg + 1, 1, n_fri, gen_w,
                                         comb_codeword.words(), n_fri));                         // :406
-        lap(tm.lde);
+        run.lap(run.tm.lde);
         std::vector<size_t> indices = fri.prove_resident(comb_codeword.words(), ps);            // :409-410
         std::sort(indices.begin(), indices.end());
-        lap(tm.fri);
+        run.lap(run.tm.fri);
 
         // ---- openings (:415-464)
         std::vector<size_t> duplicated = indices;
@@ -615,10 +774,11 @@ struct ScaledStark {
             ps.push(wire::json_field_element(element(rz_codeword, indices[k])));
             ps.push(wire::json_hash_path(rz_paths[k]));
         }
+        check_degrees(run);
         std::vector<uint8_t> proof = ps.serialize();                                            // :470
-        lap(tm.openings);
-        tm.total = std::chrono::duration<double, std::milli>(Clock::now() - t_begin).count();
-        if (timings) *timings = tm;
+        run.lap(run.tm.openings);
+        run.tm.total = std::chrono::duration<double, std::milli>(Run::Clock::now() - run.t_begin).count();
+        if (timings) *timings = run.tm;
         return proof;
     }
 
@@ -687,19 +847,22 @@ struct ScaledStark {
         for (size_t idx : indices) xs.push_back(generator * omega.pow(idx));
         std::vector<FieldElement> constant_values(indices.size() * K), tz_values(indices.size());
         if (K && !indices.empty()) {
-            if (indices.size() > 16) throw Panic("more opened points than one evaluation call takes");
             std::unique_ptr<DeviceVector> made;
             if (!prepared) made = constant_polynomials(constant_columns);
             const DeviceVector* polys = prepared ? prepared : made.get();
             if (polys->count < K * steps) throw Panic("prepared constant polynomials do not match the constant columns");
-            std::vector<uint64_t> pts(2 * xs.size()), vals(2 * K * xs.size());
-            for (size_t i = 0; i < xs.size(); i++) fe_words(xs[i], &pts[2 * i]);
-            check(stark_poly_eval_points_dev(context(), polys->words(), steps, K, steps, pts.data(), xs.size(), vals.data()));
-            for (size_t k = 0; k < K; k++)
-                for (size_t i = 0; i < xs.size(); i++) {
-                    starkf::fe v{vals[2 * (k * xs.size() + i)], vals[2 * (k * xs.size() + i) + 1]};
-                    constant_values[i * K + k] = FieldElement::wrap(v);
-                }
+            // one evaluation call takes at most 16 points (2 * num_colinearity_tests are opened)
+            for (size_t at = 0; at < xs.size(); at += 16) {
+                const size_t m = std::min<size_t>(16, xs.size() - at);
+                std::vector<uint64_t> pts(2 * m), vals(2 * K * m);
+                for (size_t i = 0; i < m; i++) fe_words(xs[at + i], &pts[2 * i]);
+                check(stark_poly_eval_points_dev(context(), polys->words(), steps, K, steps, pts.data(), m, vals.data()));
+                for (size_t k = 0; k < K; k++)
+                    for (size_t i = 0; i < m; i++) {
+                        starkf::fe v{vals[2 * (k * m + i)], vals[2 * (k * m + i) + 1]};
+                        constant_values[(at + i) * K + k] = FieldElement::wrap(v);
+                    }
+            }
         }
         {
             const size_t factors = original_trace_length - 1;

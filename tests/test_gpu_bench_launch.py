@@ -28,5 +28,7 @@ def test_bench_gpus_2_launches_two_ranks():
     extra = line["extra"]
     assert "error" not in extra, extra.get("error")
     assert "fourstep_ntt_2^24_ms" in extra and "fri_commit_2^24_sharded_ms" in extra
+    assert extra["stark_prove_2^20_sharded_ms"] > 0
+    assert extra["stark_prove_2^20_sharded_proof_sha256"] == extra["stark_proof_2^20_sha256"]     # same bytes as one GPU
     assert extra["collective"]["world"] == 2 and extra["collective"]["backend"] == "gloo"
     assert [d["rank"] for d in extra["collective"]["devices"]] == [0, 1]

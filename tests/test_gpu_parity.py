@@ -1,6 +1,7 @@
 """Parity of the HIP library (through the C ABI) with the CPU restatements.
 Bit-exact everywhere: all results are canonical integers, digests or bytes."""
 import hashlib
+import os
 
 import numpy as np
 import pytest
@@ -192,7 +193,8 @@ def test_batched_lde_commit_full_size_64_columns(ctx):
     columns): 64 x 2^20 coefficients -> 64 x 2^22 evaluations on generator * omega^i and one Merkle
     root per column, in one coset_lde_batch_dev and one merkle_roots_fe_batch_dev.  At this size the
     transform runs in scratch-bounded groups of 16 columns and the commitments in groups of trees
-    that fit 4 GiB.  First, middle and last column and their roots against the CPU restatement."""
+    that fit 4 GiB.  Every one of the 64 roots against the single-column commitment of that column (a different
+    launch path: one tree per call), and eight columns and their roots against the CPU restatement."""
     import torch
     cols, n_coeffs, n_out = 64, 1 << 20, 1 << 22
     host = oc.splitmix(cols * n_coeffs, 333).reshape(cols, n_coeffs, 2)
@@ -202,11 +204,14 @@ def test_batched_lde_commit_full_size_64_columns(ctx):
     ctx.coset_lde_batch_dev(coeffs, n_coeffs, n_coeffs, cols, n_out, G, out, n_out)
     roots = ctx.merkle_roots_fe_batch_dev(out, n_out, cols, n_out)       # returns after a synchronisation
     assert len(roots) == cols and len(set(roots)) == cols
-    for c in (0, cols // 2, cols - 1):
-        want = oc.coset_lde(np.ascontiguousarray(host[c]), n_out, G)
-        got = out[c].cpu().numpy().view(np.uint64)
-        assert np.array_equal(got, want), f"column {c}"
-        assert roots[c] == oc.merkle_commit_fe(want), f"root {c}"
+    for c in range(cols):
+        assert roots[c] == ctx.merkle_commit_fe_dev(out[c], n_out), f"root {c} differs from the single-column commitment"
+    with oc.threads(min(16, os.cpu_count() or 1)):
+        for c in (0, 1, 15, 16, 31, 32, 47, cols - 1):                   # both ends of every group of 16 columns
+            want = oc.coset_lde(np.ascontiguousarray(host[c]), n_out, G)
+            got = out[c].cpu().numpy().view(np.uint64)
+            assert np.array_equal(got, want), f"column {c}"
+            assert roots[c] == oc.merkle_commit_fe(want), f"root {c}"
     del coeffs, out
     torch.cuda.empty_cache()
 

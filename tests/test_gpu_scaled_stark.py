@@ -161,8 +161,10 @@ def test_mpoly_eval_rescue_constraints(ctx):
         assert len(terms) > 20 and all(len(k) <= nv for _, k in terms)
         out = _dev(np.zeros((n, 2), dtype=np.uint64))
         ctx.mpoly_eval_dev(ptrs, rot, terms, out, n)
+        ctx.synchronize()                                 # the call only queues (its table goes up through a staging slot)
         got = oc.to_ints(_host(out))
         ctx.mpoly_eval_dev(ptrs, rot, terms, out, n, mul_ptr=dm)
+        ctx.synchronize()
         got_mul = oc.to_ints(_host(out))
         for i in list(range(0, n, 37)) + [n - 3, n - 2, n - 1]:
             point = [ints[0][i], ints[1][i], ints[2][i], ints[1][(i + 3) % n], ints[2][(i + 3) % n]] + \
@@ -172,6 +174,7 @@ def test_mpoly_eval_rescue_constraints(ctx):
     # exponents beyond the AIR's: x^200 * y^2 + 5
     out = _dev(np.zeros((n, 2), dtype=np.uint64))
     ctx.mpoly_eval_dev([d[0], d[1]], None, [(1, (200, 2)), (5, (0, 0))], out, n)
+    ctx.synchronize()
     got = oc.to_ints(_host(out))
     for i in (0, 1, n - 1):
         assert got[i] == (pow(ints[0][i], 200, P) * pow(ints[1][i], 2, P) + 5) % P
@@ -179,10 +182,23 @@ def test_mpoly_eval_rescue_constraints(ctx):
 
 def test_poly_degree(ctx):
     """Polynomial::degree (univariate_poly.rs:69-85) on lowest-first coefficients."""
+    import torch
     n = 1 << 16
     x = np.zeros((n, 2), dtype=np.uint64)
     d = _dev(x)
     assert ctx.poly_degree_dev(d, n) == (0, True)
+    # the posted form: 0 for the zero polynomial, else degree + 1, left on the device
+    word = torch.full((3,), -1, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    ctx.poly_degree_post_dev(d, n, word[0:])
+    y = x.copy()
+    y[12345] = oc.fe(7)
+    d2 = _dev(y)
+    ctx.poly_degree_post_dev(d2, n, word[1:])
+    y[0] = oc.fe(1)
+    ctx.poly_degree_post_dev(_dev(y[:1]), 1, word[2:])
+    ctx.synchronize()
+    assert word.cpu().tolist() == [0, 12346, 1]
     x[0] = oc.fe(9)
     assert ctx.poly_degree_dev(_dev(x), n) == (0, False)
     x[40000, 1] = 1                                       # a value whose low word is zero
@@ -391,6 +407,23 @@ def test_2_20_rows_both_verifiers(hm):
         st = ss.ScaledStark(4, 2, 2, rp.m, rows)
         air, cols = ss.rescue_column_air(rp), ss.rescue_constant_columns(rp, rows)
         assert st.verify(proof, air, cols, ss.rescue_chain_boundary(rp, rows, job.output))
+    finally:
+        job.free()
+
+
+def test_more_than_sixteen_opened_points(hm):
+    """Nine colinearity tests open eighteen points: the verifier's evaluation of the constant columns' polynomials
+    takes them in runs of sixteen."""
+    job = _Chain(hm, 5, 64, 4, 9, 2)
+    try:
+        random = hashlib.shake_256(b"nine tests").digest(job.random_bytes)
+        proof, _ = job.prove(random)
+        assert job.verify(job.output, proof) == 1
+        assert job.verify((job.output + 1) % P, proof) == 0
+        rp = sp.RescuePrime()
+        st = ss.ScaledStark(4, 9, 2, rp.m, 64)
+        assert st.verify(proof, ss.rescue_column_air(rp), ss.rescue_constant_columns(rp, 64),
+                         ss.rescue_chain_boundary(rp, 64, job.output))
     finally:
         job.free()
 
