@@ -118,6 +118,12 @@ int32_t stark_vec_mul(stark_ctx* ctx, const uint64_t* a, const uint64_t* b, uint
 int32_t stark_vec_mul_dev(stark_ctx* ctx, const uint64_t* a_dev, const uint64_t* b_dev, uint64_t* out_dev,
                           size_t n);
 
+/* `count` elements of a resident vector of n elements, vec_dev[indices[k]], into host memory in one round trip: the
+ * leaves Stark::prove reveals at the opened indices (stark.rs:433,455).  indices and out are host arrays.
+ * Synchronises. */
+int32_t stark_vec_read_dev(stark_ctx* ctx, const uint64_t* vec_dev, size_t n, const uint64_t* indices, size_t count,
+                           uint64_t* out);
+
 /* ---- polynomials as vectors ------------------------------------------------
  * The algebra of Stark::prove (stark.rs:223-471) on polynomials too long for the
  * reference's O(n^2) forms: a polynomial is a coefficient vector (lowest degree

@@ -55,6 +55,8 @@ extern "C" {
                                      out_dev: *mut u64, out_stride: usize) -> i32;
     pub fn stark_vec_mul(ctx: *mut StarkCtx, a: *const u64, b: *const u64, out: *mut u64, n: usize) -> i32;
     pub fn stark_vec_mul_dev(ctx: *mut StarkCtx, a_dev: *const u64, b_dev: *const u64, out_dev: *mut u64, n: usize) -> i32;
+    pub fn stark_vec_read_dev(ctx: *mut StarkCtx, vec_dev: *const u64, n: usize, indices: *const u64, count: usize,
+                              out: *mut u64) -> i32;
     pub fn stark_poly_compose_linear_dev(ctx: *mut StarkCtx, coeffs_dev: *mut u64, n: usize, n_cols: usize,
                                          col_stride: usize, s: *const u64) -> i32;
     pub fn stark_coset_interpolate_batch_dev(ctx: *mut StarkCtx, data_dev: *mut u64, n: usize, n_cols: usize,

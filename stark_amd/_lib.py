@@ -39,6 +39,7 @@ SIGNATURES = {
     "stark_ntt_batch_dev": (i32, [C.c_void_p, C.c_void_p, sz, sz, sz, i32]),
     "stark_coset_lde_batch": (i32, [C.c_void_p, C.c_void_p, sz, sz, sz, sz, u64p, C.c_void_p, sz]),
     "stark_coset_lde_batch_dev": (i32, [C.c_void_p, C.c_void_p, sz, sz, sz, sz, u64p, C.c_void_p, sz]),
+    "stark_vec_read_dev": (i32, [C.c_void_p, C.c_void_p, sz, C.c_void_p, sz, C.c_void_p]),
     "stark_poly_compose_linear_dev": (i32, [C.c_void_p, C.c_void_p, sz, sz, sz, u64p]),
     "stark_coset_interpolate_batch_dev": (i32, [C.c_void_p, C.c_void_p, sz, sz, sz, u64p]),
     "stark_vec_inv_dev": (i32, [C.c_void_p, C.c_void_p, C.c_void_p, sz]),

@@ -585,7 +585,7 @@ static bool is_canonical(fe x) { return !ge_p(x.lo, x.hi); }
 constexpr size_t SMALL_IO_BYTES = (size_t)64 << 10;
 constexpr size_t LANE_CHUNK = (size_t)4 << 20;
 constexpr size_t LANE_COUNT = 4;
-constexpr size_t LANE_THRESHOLD = (size_t)32 << 20;    // smaller transfers go through the runtime
+constexpr size_t LANE_THRESHOLD = (size_t)8 << 20;     // smaller transfers go through the runtime
 
 static hipError_t lanes_init(stark_ctx* ctx)
 {
@@ -1888,6 +1888,24 @@ extern "C" int32_t stark_fri_layer_read(stark_fri_layers* l, size_t layer, const
     ST_TRY(dov.alloc(count * sizeof(fe)));
     HIP_TRY(hipMemcpyAsync(di.p, indices, count * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(launch_gather_fe(l->cw[layer], (const uint64_t*)di.p, (fe*)dov.p, count, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(out, dov.p, count * sizeof(fe), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return STARK_OK;
+}
+
+extern "C" int32_t stark_vec_read_dev(stark_ctx* ctx, const uint64_t* vec_dev, size_t n, const uint64_t* indices,
+                                      size_t count, uint64_t* out)
+{
+    CtxGuard guard_(ctx);
+    if (!ctx || (count && (!vec_dev || !indices || !out))) return fail(STARK_EARG, "null argument");
+    if (count == 0) return STARK_OK;
+    for (size_t i = 0; i < count; i++)
+        if (indices[i] >= n) return fail(STARK_EINDEX, "codeword index out of range");
+    DevBuf di(ctx), dov(ctx);
+    ST_TRY(di.alloc(count * sizeof(uint64_t)));
+    ST_TRY(dov.alloc(count * sizeof(fe)));
+    HIP_TRY(hipMemcpyAsync(di.p, indices, count * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(launch_gather_fe((const fe*)vec_dev, (const uint64_t*)di.p, (fe*)dov.p, count, ctx->stream));
     HIP_TRY(hipMemcpyAsync(out, dov.p, count * sizeof(fe), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return STARK_OK;

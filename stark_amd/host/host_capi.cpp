@@ -425,11 +425,11 @@ struct ChainJob {
     std::vector<std::vector<FieldElement>> trace, constants;
     std::vector<FieldElement> columns;               // the trace by columns (register s at s * rows), made on first use
     std::vector<MPolynomial> air;
-    std::unique_ptr<DeviceVector> constant_polys;    // the statement's public polynomials, made once
+    std::unique_ptr<ScaledStark::Prepared> constant_polys;   // the statement's public polynomials, made once
     bool use_prepared = true;                        // off: prove and verify interpolate the constant columns themselves
     ChainJob(const FieldElement& input, size_t rows, size_t expansion, size_t ncol, size_t security)
         : chain(rows), stark(expansion, ncol, security, chain.rp.m, rows), trace(chain.trace(input)),
-          constants(chain.constant_columns()), air(chain.air()), constant_polys(stark.constant_polynomials(constants))
+          constants(chain.constant_columns()), air(chain.air()), constant_polys(stark.prepare(constants))
     {
     }
     ScaledStark::TraceColumns trace_columns()

@@ -194,7 +194,8 @@ struct ScaledStark {
     GeometricDomain geo;
     // kept from one proof to the next: the transition zeroifier's coefficients on the device (they depend
     // on the trace length only) and the staging buffer of the randomizer's raw bytes
-    mutable std::unique_ptr<DeviceVector> tz_coeffs;
+    mutable std::unique_ptr<DeviceVector> tz_coeffs, coset_x, coset_tz_inv;
+    mutable size_t coset_n_q = 0;
     mutable std::vector<uint8_t> random_staging;
     mutable std::vector<FieldElement> column_staging;         // the trace by columns, on its way to the device
     mutable std::mutex staging_mu;
@@ -315,6 +316,22 @@ struct ScaledStark {
         return out;
     }
 
+    // What depends on the statement only, made once and handed to every proof and verification of it: the
+    // constant columns' polynomials and, from the first proof on, their values on the coset the transition
+    // quotients are computed on.  (The reference receives the round-constant polynomials inside its transition
+    // constraints, made by rescue_prime.rs:309-359 before Stark::prove is called.)
+    struct Prepared {
+        std::unique_ptr<DeviceVector> polys;                    // column k at words(k * (T - 1))
+        mutable std::unique_ptr<DeviceVector> coset_values;     // column k at words(k * n_q)
+        mutable size_t n_q = 0;
+    };
+    std::unique_ptr<Prepared> prepare(const std::vector<std::vector<FieldElement>>& columns) const
+    {
+        std::unique_ptr<Prepared> p(new Prepared());
+        p->polys = constant_polynomials(columns);
+        return p;
+    }
+
     // term table of one constraint for stark_mpoly_eval_dev
     struct TermTable {
         size_t n_vars = 0;
@@ -362,6 +379,7 @@ struct ScaledStark {
         std::unique_ptr<DeviceVector> tp, bq, tq, randomizer, combination, made, posted;
         std::unique_ptr<DeviceBuffer> raw_random;
         const DeviceVector* constants = nullptr;
+        const Prepared* prepared = nullptr;
         std::vector<size_t> bq_bounds, tq_bounds;
         std::future<void> drawn;
         Run() = default;
@@ -413,7 +431,7 @@ struct ScaledStark {
     // `run` must stay alive until randomizer_polynomial() or the Run's destructor has joined it.
     void begin(Run& run, const TraceColumns& trace, const std::vector<MPolynomial>& air, size_t n_constant_columns,
                const std::vector<BoundaryCondition>& boundary, const RandomSource& rng,
-               const DeviceVector* prepared_constants) const
+               const Prepared* prepared_constants) const
     {
         stark_ctx* ctx = context();
         run.busy = std::unique_lock<std::mutex>(prove_mu);
@@ -466,7 +484,8 @@ struct ScaledStark {
         // ---- interpolation (:260-275)
         geo.interpolate(trace_values.words(), n_rows, R, n_rows, run.tp->words(), n_rows);
         if (prepared_constants) {
-            run.constants = prepared_constants;
+            run.prepared = prepared_constants;
+            run.constants = prepared_constants->polys.get();
             if (run.constants->count < std::max<size_t>(1, run.K * (T - 1)))
                 throw Panic("prepared constant polynomials do not match the constant columns");
         }
@@ -516,6 +535,7 @@ struct ScaledStark {
                               const std::vector<std::vector<FieldElement>>& constant_columns) const
     {
         stark_ctx* ctx = context();
+        run.mark = Run::Clock::now();                         // what the caller did since the last step is not this step's
         const size_t R = run.R, T = run.T, n_rows = run.n_rows, K = run.K, n_vars = run.n_vars, n_o = omicron_domain_length;
         uint64_t gen_w[2];
         fe_words(generator, gen_w);
@@ -531,29 +551,55 @@ struct ScaledStark {
         run.tq.reset(new DeviceVector(air.size() * n_q));
         DeviceVector& tq = *run.tq;
         {
-            DeviceVector cols(n_vars * n_q), tz_values(n_q), x_poly(2);
-            x_poly.upload({FieldElement::zero(), FieldElement::one()});
-            check(stark_coset_lde_batch_dev(ctx, x_poly.words(), 2, 2, 1, n_q, gen_w, cols.words(0), n_q));
-            check(stark_coset_lde_batch_dev(ctx, run.tp->words(), n_rows, n_rows, R, n_q, gen_w, cols.words(n_q), n_q));
-            if (K)
-                check(stark_coset_lde_batch_dev(ctx, run.constants->words(), T - 1, T - 1, K, n_q, gen_w,
-                                                cols.words((1 + R) * n_q), n_q));
-            if (!tz_coeffs) {
-                tz_coeffs.reset(new DeviceVector(T));
-                tz_coeffs->upload(geo.zeroifier(T - 1));       // :134-137
+            // values on the coset that do not depend on the trace are kept from proof to proof: x itself and the
+            // transition zeroifier's inverse (they depend on the trace length and the constraints' degree only) in
+            // this object, the constant columns' values with the prepared statement
+            if (coset_n_q != n_q) {
+                coset_x.reset(new DeviceVector(n_q));
+                coset_tz_inv.reset(new DeviceVector(n_q));
+                DeviceVector x_poly(2);
+                x_poly.upload({FieldElement::zero(), FieldElement::one()});
+                check(stark_coset_lde_batch_dev(ctx, x_poly.words(), 2, 2, 1, n_q, gen_w, coset_x->words(), n_q));
+                if (!tz_coeffs) {
+                    tz_coeffs.reset(new DeviceVector(T));
+                    tz_coeffs->upload(geo.zeroifier(T - 1));   // :134-137
+                }
+                check(stark_coset_lde_batch_dev(ctx, tz_coeffs->words(), T, T, 1, n_q, gen_w, coset_tz_inv->words(), n_q));
+                check(stark_vec_inv_dev(ctx, coset_tz_inv->words(), coset_tz_inv->words(), n_q));
+                check(stark_ctx_synchronize(ctx));
+                coset_n_q = n_q;
             }
-            check(stark_coset_lde_batch_dev(ctx, tz_coeffs->words(), T, T, 1, n_q, gen_w, tz_values.words(), n_q));
-            check(stark_vec_inv_dev(ctx, tz_values.words(), tz_values.words(), n_q));
+            std::unique_ptr<DeviceVector> own_constants;
+            const DeviceVector* constant_values = nullptr;
+            if (K) {
+                if (run.prepared) {
+                    if (run.prepared->n_q != n_q) {
+                        run.prepared->coset_values.reset(new DeviceVector(K * n_q));
+                        check(stark_coset_lde_batch_dev(ctx, run.constants->words(), T - 1, T - 1, K, n_q, gen_w,
+                                                        run.prepared->coset_values->words(), n_q));
+                        run.prepared->n_q = n_q;
+                    }
+                    constant_values = run.prepared->coset_values.get();
+                } else {
+                    own_constants.reset(new DeviceVector(K * n_q));
+                    check(stark_coset_lde_batch_dev(ctx, run.constants->words(), T - 1, T - 1, K, n_q, gen_w,
+                                                    own_constants->words(), n_q));
+                    constant_values = own_constants.get();
+                }
+            }
+            DeviceVector cols(R * n_q);
+            check(stark_coset_lde_batch_dev(ctx, run.tp->words(), n_rows, n_rows, R, n_q, gen_w, cols.words(), n_q));
+            const DeviceVector& tz_values = *coset_tz_inv;
             // variables: x, registers now, registers one step on (rotation), constants
             std::vector<const uint64_t*> ptrs(n_vars);
             std::vector<size_t> rot(n_vars, 0);
-            ptrs[0] = cols.words(0);
+            ptrs[0] = coset_x->words();
             for (size_t s = 0; s < R; s++) {
-                ptrs[1 + s] = cols.words((1 + s) * n_q);
-                ptrs[1 + R + s] = cols.words((1 + s) * n_q);
+                ptrs[1 + s] = cols.words(s * n_q);
+                ptrs[1 + R + s] = cols.words(s * n_q);
                 rot[1 + R + s] = omicron_places;
             }
-            for (size_t k = 0; k < K; k++) ptrs[1 + 2 * R + k] = cols.words((1 + R + k) * n_q);
+            for (size_t k = 0; k < K; k++) ptrs[1 + 2 * R + k] = constant_values->words(k * n_q);
             for (size_t a = 0; a < air.size(); a++) {
                 TermTable tt = term_table(air[a], n_vars);
                 check(stark_mpoly_eval_dev(ctx, n_vars, ptrs.data(), rot.data(), tt.coeffs.size() / 2, tt.coeffs.data(),
@@ -571,6 +617,7 @@ struct ScaledStark {
     void randomizer_polynomial(Run& run) const
     {
         stark_ctx* ctx = context();
+        run.mark = Run::Clock::now();
         run.randomizer.reset(new DeviceVector(run.max_deg + 1));
         run.drawn.get();                                      // rethrows what the random source threw
         check(stark_sample_bytes_dev(ctx, (const uint8_t*)run.raw_random->p, 17, run.max_deg + 1, 1, run.randomizer->words()));
@@ -581,6 +628,7 @@ struct ScaledStark {
     void combine(Run& run, const std::vector<uint8_t>& challenge) const
     {
         stark_ctx* ctx = context();
+        run.mark = Run::Clock::now();
         const size_t R = run.R, n_air = run.n_air, max_deg = run.max_deg;
         std::vector<FieldElement> weights = sample_weights(1 + 2 * n_air + 2 * R, challenge);
         run.combination.reset(new DeviceVector(max_deg + 1));
@@ -654,7 +702,7 @@ struct ScaledStark {
     std::vector<uint8_t> prove(const std::vector<std::vector<FieldElement>>& trace, const std::vector<MPolynomial>& air,
                                const std::vector<std::vector<FieldElement>>& constant_columns,
                                const std::vector<BoundaryCondition>& boundary, const RandomSource& rng,
-                               ProveTimings* timings = nullptr, const DeviceVector* prepared = nullptr) const
+                               ProveTimings* timings = nullptr, const Prepared* prepared = nullptr) const
     {
         const auto t0 = std::chrono::steady_clock::now();
         if (trace.size() != original_trace_length) throw Panic("trace length differs from the one this Stark was made for");
@@ -696,7 +744,7 @@ struct ScaledStark {
     std::vector<uint8_t> prove_columns(const TraceColumns& trace, const std::vector<MPolynomial>& air,
                                        const std::vector<std::vector<FieldElement>>& constant_columns,
                                        const std::vector<BoundaryCondition>& boundary, const RandomSource& rng,
-                                       ProveTimings* timings = nullptr, const DeviceVector* prepared = nullptr) const
+                                       ProveTimings* timings = nullptr, const Prepared* prepared = nullptr) const
     {
         Run run;
         try {
@@ -710,7 +758,7 @@ struct ScaledStark {
     std::vector<uint8_t> prove_steps(Run& run, const TraceColumns& trace, const std::vector<MPolynomial>& air,
                                      const std::vector<std::vector<FieldElement>>& constant_columns,
                                      const std::vector<BoundaryCondition>& boundary, const RandomSource& rng,
-                                     ProveTimings* timings, const DeviceVector* prepared) const
+                                     ProveTimings* timings, const Prepared* prepared) const
     {
         stark_ctx* ctx = context();
         const size_t R = num_registers, n_fri = fri_domain_length;
@@ -761,17 +809,23 @@ struct ScaledStark {
         for (size_t i : indices) duplicated.push_back((i + expansion_factor) % n_fri);
         std::sort(duplicated.begin(), duplicated.end());
         const std::vector<uint64_t> dup64(duplicated.begin(), duplicated.end()), idx64(indices.begin(), indices.end());
-        auto element = [&](const DeviceVector& v, size_t at) { return v.download(at, 1)[0]; };
+        auto elements = [&](const uint64_t* codeword, const std::vector<uint64_t>& at) {
+            std::vector<FieldElement> v(at.size());
+            check(stark_vec_read_dev(ctx, codeword, n_fri, at.data(), at.size(), (uint64_t*)v.data()));
+            return v;
+        };
         for (size_t s = 0; s < R; s++) {
             const std::vector<std::vector<HashOutput>> paths = Merkle::open_tree_many(bq_trees[s]->t, dup64);
+            const std::vector<FieldElement> leaves = elements(bq_codewords.words(s * n_fri), dup64);
             for (size_t k = 0; k < duplicated.size(); k++) {
-                ps.push(wire::json_field_element(element(bq_codewords, s * n_fri + duplicated[k])));
+                ps.push(wire::json_field_element(leaves[k]));
                 ps.push(wire::json_hash_path(paths[k]));
             }
         }
         const std::vector<std::vector<HashOutput>> rz_paths = Merkle::open_tree_many(rz_tree.t, idx64);
+        const std::vector<FieldElement> rz_leaves = elements(rz_codeword.words(), idx64);
         for (size_t k = 0; k < indices.size(); k++) {
-            ps.push(wire::json_field_element(element(rz_codeword, indices[k])));
+            ps.push(wire::json_field_element(rz_leaves[k]));
             ps.push(wire::json_hash_path(rz_paths[k]));
         }
         check_degrees(run);
@@ -785,7 +839,7 @@ struct ScaledStark {
     // Stark::verify (:474-723) with the constant columns' polynomials evaluated at the opened points
     bool verify(const std::vector<uint8_t>& proof, const std::vector<MPolynomial>& air,
                 const std::vector<std::vector<FieldElement>>& constant_columns,
-                const std::vector<BoundaryCondition>& boundary, const DeviceVector* prepared = nullptr) const
+                const std::vector<BoundaryCondition>& boundary, const Prepared* prepared = nullptr) const
     {
         size_t max_cycle = 0;
         for (const auto& b : boundary) max_cycle = std::max(max_cycle, std::get<0>(b));
@@ -849,7 +903,7 @@ struct ScaledStark {
         if (K && !indices.empty()) {
             std::unique_ptr<DeviceVector> made;
             if (!prepared) made = constant_polynomials(constant_columns);
-            const DeviceVector* polys = prepared ? prepared : made.get();
+            const DeviceVector* polys = prepared ? prepared->polys.get() : made.get();
             if (polys->count < K * steps) throw Panic("prepared constant polynomials do not match the constant columns");
             // one evaluation call takes at most 16 points (2 * num_colinearity_tests are opened)
             for (size_t at = 0; at < xs.size(); at += 16) {
