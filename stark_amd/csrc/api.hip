@@ -54,6 +54,7 @@ struct NttTables {
     tw5* hi = nullptr;
     tw5* lo = nullptr;               // omega^i, i < 2^h; times n^-1 for the inverse
     int32_t* plane = nullptr;        // outgoing twiddles of the pass before the last, 5 limbs per element (built on first use)
+    fe* plane16 = nullptr;           // the same twiddles as canonical 16-byte values (see PassArgs::plane16)
     bool plane_refused = false;      // the allocation failed once: do not try again
     fe* small = nullptr;             // omega_n^i, i < n/2 (n <= 4096), Montgomery form (2^128)
     fe scale_m{0, 0};                // n^-1, Montgomery form (2^128)
@@ -94,6 +95,11 @@ static __device__ __align__(256) unsigned char scratch[2 * STATIC_TREE_MAX_LEAVE
 
 struct stark_ctx {
     int device = 0;
+    // Sizes from 2^this on keep the twiddle plane of the pass before the last as canonical 16-byte values instead
+    // of five limbs (20 bytes): measured 0.5 % faster at 2^24 and 1.6 % at 2^26, where that pass is at the
+    // memory system's ceiling, no different at 2^22 and 1 % slower below (tools/plane16_ab.py), and a fifth
+    // less table memory.  STARK_NTT_PLANE16_FROM overrides (a value above 30 turns it off).
+    uint32_t plane16_min_log = 24;
     void* static_scratch = nullptr;                    // device address of `scratch` on this context's device
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
@@ -344,10 +350,11 @@ static std::vector<uint32_t> plan_radices(uint32_t log_n)
 static void free_ntt_tables(NttTables& t)
 {
     (void)hipFree(t.tw256); (void)hipFree(t.hi); (void)hipFree(t.lo);
-    (void)hipFree(t.small); (void)hipFree(t.plane);
+    (void)hipFree(t.small); (void)hipFree(t.plane); (void)hipFree(t.plane16);
     t.tw256 = t.hi = t.lo = nullptr;
     t.small = nullptr;
     t.plane = nullptr;
+    t.plane16 = nullptr;
 }
 
 static int32_t get_ntt_tables(stark_ctx* ctx, uint32_t log_n, bool inverse, const NttTables** out)
@@ -549,7 +556,21 @@ static int32_t run_ntt(stark_ctx* ctx, const fe* src, size_t src_stride, size_t 
             if (a.next_is_last && log_n <= PLANE_MAX_LOG) {
                 // the twiddle plane of this pass: 20 bytes per element, built once per size
                 NttTables* tm = const_cast<NttTables*>(tf);
-                if (!tm->plane && !tm->plane_refused) {
+                if (ctx->plane16_min_log && log_n >= ctx->plane16_min_log) {
+                    if (!tm->plane16 && !tm->plane_refused) {
+                        if (hipMalloc((void**)&tm->plane16, (size_t)16 << log_n) != hipSuccess) {
+                            (void)hipGetLastError();
+                            tm->plane16 = nullptr;
+                            tm->plane_refused = true;
+                        } else if (launch_ntt_plane16(a, tm->plane16, ctx->stream) != hipSuccess) {
+                            (void)hipGetLastError();
+                            (void)hipFree(tm->plane16);
+                            tm->plane16 = nullptr;
+                            tm->plane_refused = true;
+                        }
+                    }
+                    a.plane16 = tm->plane16;
+                } else if (!tm->plane && !tm->plane_refused) {
                     if (hipMalloc((void**)&tm->plane, (size_t)20 << log_n) != hipSuccess) {
                         (void)hipGetLastError();          // no room: this size keeps forming hi*lo per element
                         tm->plane = nullptr;
@@ -928,6 +949,7 @@ extern "C" int32_t stark_ctx_create(int32_t device, stark_ctx** out)
         return fail(STARK_EHIP, std::string("stark_ctx_create: ") + hipGetErrorString(e));
     }
     ctx->stream = ctx->own_stream;
+    if (const char* e = std::getenv("STARK_NTT_PLANE16_FROM")) ctx->plane16_min_log = (uint32_t)std::atoi(e);
     *out = ctx;
     return STARK_OK;
 }
@@ -1796,7 +1818,7 @@ static int32_t fri_commit_impl(stark_ctx* ctx, const fe* cw_src, bool src_is_hos
         const uint32_t log_N = (uint32_t)log2_exact(N);
         if (src_is_host) FRI_HIP(launch_leaf_levels(L->cw[0], N, nullptr, L->tree[0], log_N, 1, ctx->stream, &level, &m));
         else FRI_HIP(launch_leaf_levels(cw_src, N, L->cw[0], L->tree[0], log_N, 1, ctx->stream, &level, &m));   // device source: copy in the hash pass
-        FRI_HIP(launch_merkle_reduce(level, m, ctx->stream, root_mail));                                   // fri.rs:119
+        FRI_HIP(launch_merkle_reduce(level, m, ctx->stream, root_mail));                                  // fri.rs:119
     }
     // 2^-1 alpha offset_r^-1 per round: the two inverses are taken once (a Fermat inverse is ~400
     // host multiplications) and offset_r^-1 = (offset^-1)^(2^r) follows by squaring (fri.rs:142)
@@ -1824,7 +1846,7 @@ static int32_t fri_commit_impl(stark_ctx* ctx, const fe* cw_src, bool src_is_hos
         a.c_m = F.to_mont(F.mul(F.mul(two_inv, alpha), offset_inv_r));
         a.half = n / 2;
         a.shift = (uint32_t)r;
-        FRI_HIP(launch_fri_fold_commit(a, ctx->stream, root_mail));                                    // fri.rs:133-139,119
+        FRI_HIP(launch_fri_fold_commit(a, ctx->stream, root_mail));                                   // fri.rs:133-139,119
         offset_inv_r = F.mul(offset_inv_r, offset_inv_r);
     }
 #undef FRI_HIP

@@ -48,9 +48,13 @@ struct PassArgs {
     // range.  If set, plane[5 i .. 5 i + 4] holds the five limbs of the twiddle of output element i
     // (same index as dst); otherwise the kernel multiplies hi and lo entries together per element.
     const int32_t* plane;
+    // The same twiddles as canonical 16-byte values (plane16[i] = the twiddle of output element i times 2^156 mod p):
+    // aligned records and a fifth less traffic for nine more instructions per element to cut them into limbs.
+    const fe* plane16;
 };
 // Fills the plane of the pass described by `a` (n = 2^log_n entries of five limbs).
 hipError_t launch_ntt_plane(const PassArgs& a, int32_t* plane, hipStream_t s);
+hipError_t launch_ntt_plane16(const PassArgs& a, fe* plane16, hipStream_t s);
 // All tw5 tables hold Montgomery forms w * 2^156 mod p as five 26-bit limbs.
 
 enum PassMode { PASS_FIRST = 0, PASS_MIDDLE = 1, PASS_LAST = 2 };

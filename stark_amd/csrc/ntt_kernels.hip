@@ -408,6 +408,25 @@ __device__ __forceinline__ void round2_store(fe5 (&v)[16], const PassArgs& a, ui
                     if (live) dst[base + ((uint64_t)k << a.log_s)] = o;
                 }
             }
+        } else if constexpr (NEXT_LAST == 3) {
+            // the same from the plane of canonical 16-byte values
+            const fe* __restrict__ plane16 = a.plane16;
+            fe w[2];
+            auto issue = [&](int kb) {
+                uint32_t k = ka2 + M1 * kb;
+                asm volatile("" : "+v"(k));
+                w[kb & 1] = plane16[base + ((uint64_t)k << a.log_s)];
+            };
+            ntt_dif_reg<4, 0, false>(v);
+            issue(0);
+#pragma clang loop unroll(full)
+            for (int kb = 0; kb < 16; kb++) {
+                if (kb + 1 < 16) issue(kb + 1);
+                uint32_t k = ka2 + M1 * kb;
+                asm volatile("" : "+v"(k));
+                const fe o = finish(mont_mul5_v(v[brev_c(kb, 4)], unpack5(w[kb & 1])));
+                if (live) dst[base + ((uint64_t)k << a.log_s)] = o;
+            }
         } else if constexpr (NEXT_LAST == 1) {
             // S_next = 1: exponent j_next * K, split over the hi and lo tables
             constexpr int B = 1;
@@ -485,6 +504,27 @@ __global__ __launch_bounds__(256) void ntt_plane_kernel(PassArgs a, int32_t* __r
     for (int l = 0; l < 5; l++) plane[5 * i + l] = w.l[l];
 }
 
+__global__ __launch_bounds__(256) void ntt_plane16_kernel(PassArgs a, fe* __restrict__ plane16)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >> a.log_n) return;
+    const uint32_t j_next = (uint32_t)(i & (((uint64_t)1 << a.log_s) - 1));
+    const uint32_t k = (uint32_t)(i >> a.log_s) & ((1u << a.r) - 1);
+    const uint32_t pre = (uint32_t)(i >> (a.r + a.log_s));
+    uint32_t bits_prev = 0;
+    for (uint32_t u = 0; u < a.nprev; u++) bits_prev += a.rprev[u];
+    const uint32_t E = j_next * (prefix_to_k(pre, a) + (k << bits_prev));
+    const tw5 wh = a.hi[E >> a.h];
+    plane16[i] = finish(mont_mul5_v(*(const fe5*)&wh, a.lo[E & ((1u << a.h) - 1)]));
+}
+
+hipError_t launch_ntt_plane16(const PassArgs& a, fe* plane16, hipStream_t s)
+{
+    const uint64_t n = (uint64_t)1 << a.log_n;
+    hipLaunchKernelGGL(ntt_plane16_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, a, plane16);
+    return hipGetLastError();
+}
+
 hipError_t launch_ntt_plane(const PassArgs& a, int32_t* plane, hipStream_t s)
 {
     const uint64_t n = (uint64_t)1 << a.log_n;
@@ -554,11 +594,13 @@ template <int RA, bool SMALL>
 static hipError_t launch_first(const PassArgs& a, bool twist, int nl, hipStream_t s)
 {
     if (twist) {
+        if (nl == 3) return launch_one<RA, PASS_FIRST, true, 3, SMALL>(a, s);
         if (nl == 2) return launch_one<RA, PASS_FIRST, true, 2, SMALL>(a, s);
         if (nl == 1) return launch_one<RA, PASS_FIRST, true, 1, SMALL>(a, s);
         if constexpr (RA == 0) return hipErrorInvalidValue;    // a radix-16 pass is always followed by the last pass
         else return launch_one<RA, PASS_FIRST, true, 0, SMALL>(a, s);
     }
+    if (nl == 3) return launch_one<RA, PASS_FIRST, false, 3, SMALL>(a, s);
     if (nl == 2) return launch_one<RA, PASS_FIRST, false, 2, SMALL>(a, s);
     if (nl == 1) return launch_one<RA, PASS_FIRST, false, 1, SMALL>(a, s);
     if constexpr (RA == 0) return hipErrorInvalidValue;
@@ -573,14 +615,15 @@ static hipError_t launch_ra(const PassArgs& a, PassMode mode, bool twist, hipStr
 {
     constexpr bool FIRST_ONLY = RA == 0;
     constexpr bool LAST_ONLY = SMALL && RA >= 3;
-    const int nl = a.next_is_last ? (a.plane ? 2 : 1) : 0;
+    const int nl = a.next_is_last ? (a.plane16 ? 3 : a.plane ? 2 : 1) : 0;
     if (mode == PASS_FIRST) {
         if constexpr (LAST_ONLY) return hipErrorInvalidValue;
         else return launch_first<RA, SMALL>(a, twist, nl, s);
     }
     if (mode == PASS_MIDDLE) {
         if constexpr (SMALL || FIRST_ONLY) return hipErrorInvalidValue;
-        else return nl == 2 ? launch_one<RA, PASS_MIDDLE, false, 2, false>(a, s)
+        else return nl == 3 ? launch_one<RA, PASS_MIDDLE, false, 3, false>(a, s)
+                    : nl == 2 ? launch_one<RA, PASS_MIDDLE, false, 2, false>(a, s)
                     : nl == 1 ? launch_one<RA, PASS_MIDDLE, false, 1, false>(a, s)
                               : launch_one<RA, PASS_MIDDLE, false, 0, false>(a, s);
     }

@@ -58,7 +58,7 @@ def lde_to_shares(engine, coeffs: torch.Tensor, n_out: int, offset: int, period:
     cols, n_coeffs, _ = coeffs.shape
     q = n_out // period
     c = period // world
-    if world == 1 or q % world:
+    if not dist.is_initialized() or q % world:
         cw = engine.coset_lde(coeffs, n_out, offset)
         return torch.stack([fri_shard_of(cw[k], rank, world, period) for k in range(cols)])
     mc = -(-n_coeffs // q)                                            # k_hi < mc <= period

@@ -348,3 +348,26 @@ def test_fourstep_two_ranks_one_gpu():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sorted(results) == [(0, True), (1, True)]
+
+
+def test_sharded_prove_over_a_one_rank_rccl_group(group):
+    """The prover spread over ranks with RCCL carrying the exchanges on device tensors (all-to-all of the
+    extension, all-gather of the subtree roots), as far as one GPU can show it: a group of one rank.  The proof is
+    the plain prover's."""
+    import hashlib
+    import torch
+    from stark_amd import hostlib, scaled
+    from stark_amd import sharded_stark as S
+    from stark_amd.distributed import HipEngine
+    assert group.get_backend() == "nccl"
+    ctx = scaled.mirror_context()
+    eng = HipEngine(ctx)
+    job = scaled.ChainJob(99, 1 << 12, 4, 2, 2)
+    random = hashlib.shake_256(b"one rank of rccl").digest(job.random_bytes)
+    ref, _ = job.prove(random)
+    steps = scaled.ChainSteps(job, random, ctx)
+    proof = S.stark_prove_sharded(eng, steps, hostlib.Stream(), period=1 << 10)
+    steps.free()
+    torch.cuda.synchronize()
+    assert proof == ref and job.verify(proof)
+    job.free()
