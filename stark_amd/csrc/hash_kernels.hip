@@ -303,13 +303,44 @@ template <int CTRL> __device__ __forceinline__ u64 quad_rotate(u64 x)
     const uint32_t hi = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)(x >> 32), CTRL, 0xf, 0xf, false);
     return ((u64)hi << 32) | lo;
 }
-// quad_perm:[1,2,3,0], [2,3,0,1], [3,0,1,2]: lane i reads lane i+1, i+2, i+3 (mod 4)
-constexpr int QUAD_ROT1 = 0x39, QUAD_ROT2 = 0x4E, QUAD_ROT3 = 0x93;
+constexpr int QUAD_ROT2 = 0x4E;     // quad_perm:[2,3,0,1]: lane i reads lane i + 2 (mod 4)
 
+// A lane of the quad does not move d to line a diagonal up (or to put the columns back): the xor that consumes
+// it first reads it from the other lane itself, through its DPP operand (the 32-bit halves are written out so
+// that the compiler can fold the lane move into the xor).  b and c are first consumed by 64-bit additions, which
+// have no such operand, and are moved.  ROT = 0..3: the word comes from lane (i + ROT) mod 4.
+template <int ROT> __device__ __forceinline__ constexpr int quad_ctrl()
+{
+    return ROT == 1 ? 0x39 : ROT == 2 ? 0x4E : 0x93;      // quad_perm:[1,2,3,0], [2,3,0,1], [3,0,1,2]
+}
+// x + (the word `far` of lane i + ROT)
+template <int ROT> __device__ __forceinline__ u64 quad_add(u64 x, u64 far)
+{
+    if constexpr (ROT == 0) return x + far;
+    else return x + quad_rotate<quad_ctrl<ROT>()>(far);
+}
+// x ^ (the word `far` of lane i + ROT)
+template <int ROT> __device__ __forceinline__ u64 quad_xor(u64 x, u64 far)
+{
+    if constexpr (ROT == 0) return x ^ far;
+    else {
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)far, quad_ctrl<ROT>(), 0xf, 0xf, true) ^
+                            (uint32_t)x;
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(far >> 32), quad_ctrl<ROT>(), 0xf, 0xf,
+                                                                  true) ^ (uint32_t)(x >> 32);
+        return ((u64)hi << 32) | lo;
+    }
+}
+
+// G (RFC 7693 3.1) on this lane's a with the b, c, d that lanes i + RB, i + RC, i + RD hold
+template <int RB, int RC, int RD>
 __device__ __forceinline__ void quad_g(u64& a, u64& b, u64& c, u64& d, u64 x, u64 y)
 {
-    a = a + b + x; d = rotr64(d ^ a, 32);
-    c = c + d;     b = rotr64(b ^ c, 24);
+    if constexpr (RB != 0) b = quad_rotate<quad_ctrl<RB>()>(b);
+    a = a + b + x;
+    d = rotr64(quad_xor<RD>(a, d), 32);
+    c = quad_add<RC>(d, c);
+    b = rotr64(b ^ c, 24);
     a = a + b + y; d = rotr64(d ^ a, 16);
     c = c + d;     b = rotr64(b ^ c, 63);
 }
@@ -335,7 +366,9 @@ __device__ __forceinline__ QuadState quad_state_init(uint32_t q)
 
 // One BLAKE2b-256 compression of the t-byte message at LDS address msg
 // (sixteen words, zero padded), by the four lanes of a quad; lane q returns
-// digest word q.
+// digest word q.  After a column step lane i holds (a_i, b_i, c_i, d_i); the diagonal step of lane i works on
+// (a_i, b_(i+1), c_(i+2), d_(i+3)) and leaves its results where it computed them, so the next column step finds
+// b_i, c_i, d_i in lanes i + 3, i + 2, i + 1.
 __device__ __forceinline__ u64 quad_blake2b(const QuadState& st, uint32_t q, const uint8_t* msg, u64 t)
 {
     u64 a = st.a0, b = st.b0, c = st.c0, d = st.d0 ^ (q == 0 ? t : 0ull);
@@ -346,12 +379,11 @@ __device__ __forceinline__ u64 quad_blake2b(const QuadState& st, uint32_t q, con
         const u64 y0 = *(const u64*)(msg + ((sc >> 8) & 0xffu));
         const u64 x1 = *(const u64*)(msg + ((sc >> 16) & 0xffu));
         const u64 y1 = *(const u64*)(msg + (sc >> 24));
-        quad_g(a, b, c, d, x0, y0);
-        b = quad_rotate<QUAD_ROT1>(b); c = quad_rotate<QUAD_ROT2>(c); d = quad_rotate<QUAD_ROT3>(d);
-        quad_g(a, b, c, d, x1, y1);
-        b = quad_rotate<QUAD_ROT3>(b); c = quad_rotate<QUAD_ROT2>(c); d = quad_rotate<QUAD_ROT1>(d);
+        if (r == 0) quad_g<0, 0, 0>(a, b, c, d, x0, y0);
+        else quad_g<3, 2, 1>(a, b, c, d, x0, y0);
+        quad_g<1, 2, 3>(a, b, c, d, x1, y1);
     }
-    return st.a0 ^ a ^ c;
+    return st.a0 ^ a ^ quad_rotate<QUAD_ROT2>(c);            // c_i sits in lane i + 2 after the last diagonal step
 }
 
 // Tail of a tree: every workgroup reduces TAIL_CHILDREN consecutive digests of
