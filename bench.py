@@ -66,6 +66,8 @@ def valu_roofline(valu_wave_instr: float, seconds: float, clock_ghz_profiled=Non
         peak_p = N_SIMD * clock_ghz_profiled / 4.0
         r.update({"clock_ghz_profiled": clock_ghz_profiled, "peak_at_profiled_clock": round(peak_p, 1),
                   "frac_at_profiled_clock": round(min(rate / peak_p, 1.0), 4)})
+        if rate > peak_p:                                   # this run held a higher clock than the profiled one did
+            r["clock_above_profiled"] = True
     return r
 
 

@@ -365,3 +365,31 @@ def test_num_rounds():
     assert oc.lib.so_fri_num_rounds(512, 4, 2) == 6
     with pytest.raises(AssertionError):
         so.Fri(1, 1, 4, 4, 1)
+
+
+def test_threaded_loops_give_the_same_values():
+    """The restatement's bulk loops on several threads (the all-cores CPU baseline) against the sequential code:
+    transforms of sizes on both sides of the run length, a tree, a fold and a whole Fri::commit."""
+    for log_n in (3, 11, 13, 16):
+        x = oc.splitmix(1 << log_n, 900 + log_n)
+        one_f, one_i = oc.ntt(x), oc.ntt(x, inverse=True)
+        with oc.threads(4):
+            assert np.array_equal(oc.ntt(x), one_f) and np.array_equal(oc.ntt(x, inverse=True), one_i)
+    x = oc.splitmix(1 << 14, 77)
+    omega = so.primitive_nth_root(1 << 14)
+    tree = oc.merkle_tree_fe(x)
+    fold = oc.fri_fold(x, 12345, so.GENERATOR, omega)
+    layers, roots, alphas, _ = oc.fri_commit(x, so.GENERATOR, omega, 4, 17)
+    with oc.threads(3):
+        assert np.array_equal(oc.merkle_tree_fe(x), tree)
+        assert np.array_equal(oc.fri_fold(x, 12345, so.GENERATOR, omega), fold)
+        l2, r2, a2, _ = oc.fri_commit(x, so.GENERATOR, omega, 4, 17)
+    assert r2 == roots and a2 == alphas and all(np.array_equal(u, v) for u, v in zip(l2, layers))
+    # and the fold's runs against the literal formula of fri.rs:133-138 at a few positions
+    vals = oc.to_ints(x)
+    two_inv = so.fe_inverse(2)
+    for i in (0, 1, 4095, 4096, 4097, (1 << 13) - 1):
+        r = so.fe_div(12345, so.fe_mul(so.GENERATOR, so.fe_pow(omega, i)))
+        want = so.fe_mul(two_inv, so.fe_add(so.fe_mul(so.fe_add(1, r), vals[i]),
+                                            so.fe_mul(so.fe_sub(1, r), vals[(1 << 13) + i])))
+        assert oc.to_int(fold[i]) == want
