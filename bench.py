@@ -575,6 +575,29 @@ def main():
     # data-path collective (only the 32-byte roots are gathered); and, with more than one GPU, the
     # four-step 2^24 transform whose transposes are RCCL all-to-alls
     multi = {}
+    # A collective that never completes (a peer that died, an exchange the fabric does not finish) must not cost
+    # the headline line: past the deadline rank 0 prints what it has, and every rank leaves without waiting for the
+    # others.  Exit code 0 everywhere, so that a launcher does not count the lost side measurement as a failed run.
+    watchdog = None
+    if world > 1 and not args.no_extra:
+        import threading
+        deadline_s = float(os.environ.get("STARK_BENCH_MULTI_DEADLINE_S", "240"))
+
+        def expire():
+            if rank == 0:
+                late = dict(extra)
+                late.update(multi)
+                late["collective"] = collective
+                late["multi_gpu_error"] = ("the measurements that need every rank did not finish within %.0f s; "
+                                           "the line carries what was measured until then" % deadline_s)
+                result["cpu_baseline"] = None
+                result["extra"] = late
+                print(json.dumps(result), flush=True)
+            os._exit(0)
+
+        watchdog = threading.Timer(deadline_s, expire)
+        watchdog.daemon = True
+        watchdog.start()
     if not args.no_extra:
         try:
             from stark_amd.distributed import HipEngine, fourstep_ntt, lde_commit_columns, shard_columns
@@ -680,6 +703,8 @@ def main():
                 del xl
         except Exception as e:  # noqa: BLE001 - side measurements must not lose the headline line
             multi["error"] = repr(e)
+    if watchdog is not None:
+        watchdog.cancel()
 
     if rank == 0:
         extra.update(multi)

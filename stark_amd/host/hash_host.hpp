@@ -97,52 +97,106 @@ inline std::vector<uint8_t> blake2b(const uint8_t* p, size_t len, size_t outlen)
     return h.finalize();
 }
 
-inline std::vector<uint8_t> shake256(const uint8_t* in, size_t len, size_t outlen)
+// Keccak-f[1600] (FIPS 202, 3.2-3.3).  The lane walk of rho and pi is generated at compile time from the
+// specification ((x, y) -> (y, 2x + 3y), rotation (t + 1)(t + 2) / 2), and every loop has a constant trip
+// count and is unrolled, so the 25 lanes stay in registers: the Fiat-Shamir transcript hashes the whole
+// stream again for every challenge (proof_stream.rs:50-58), some hundred permutations per FRI proof, all
+// of them between two device launches that wait for the result.
+struct KeccakWalk {
+    int lane[24];
+    int rot[24];
+};
+constexpr KeccakWalk keccak_walk()
 {
-    static const uint64_t rc[24] = {
+    KeccakWalk w{};
+    int x = 1, y = 0;
+    for (int t = 0; t < 24; t++) {
+        const int nx = y, ny = (2 * x + 3 * y) % 5;     // where lane (x, y) goes
+        w.lane[t] = nx + 5 * ny;
+        w.rot[t] = ((t + 1) * (t + 2) / 2) % 64;        // by how much lane (x, y) is rotated on the way
+        x = nx;
+        y = ny;
+    }
+    return w;
+}
+
+#if defined(__GNUC__) && !defined(__clang__)
+__attribute__((optimize("O3", "unroll-loops")))
+#endif
+inline void keccak_f1600(uint64_t (&a)[25])
+{
+    static constexpr uint64_t rc[24] = {
         0x0000000000000001ull, 0x0000000000008082ull, 0x800000000000808aull, 0x8000000080008000ull,
         0x000000000000808bull, 0x0000000080000001ull, 0x8000000080008081ull, 0x8000000000008009ull,
         0x000000000000008aull, 0x0000000000000088ull, 0x0000000080008009ull, 0x000000008000000aull,
         0x000000008000808bull, 0x800000000000008bull, 0x8000000000008089ull, 0x8000000000008003ull,
         0x8000000000008002ull, 0x8000000000000080ull, 0x000000000000800aull, 0x800000008000000aull,
         0x8000000080008081ull, 0x8000000000008080ull, 0x0000000080000001ull, 0x8000000080008008ull};
-    static const int rot[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
-    auto rotl = [](uint64_t x, int r) { return r ? (x << r) | (x >> (64 - r)) : x; };
-    auto permute = [&](uint64_t (&a)[25]) {
-        for (int round = 0; round < 24; round++) {
-            uint64_t c[5], d[5], b[25];
-            for (int x = 0; x < 5; x++) c[x] = a[x] ^ a[x + 5] ^ a[x + 10] ^ a[x + 15] ^ a[x + 20];
-            for (int x = 0; x < 5; x++) d[x] = c[(x + 4) % 5] ^ rotl(c[(x + 1) % 5], 1);
-            for (int i = 0; i < 25; i++) a[i] ^= d[i % 5];
-            // rho + pi: B[y][(2x+3y)%5] = rot(A[x][y])
-            for (int x = 0; x < 5; x++)
-                for (int y = 0; y < 5; y++) b[y + 5 * ((2 * x + 3 * y) % 5)] = rotl(a[x + 5 * y], rot[x + 5 * y]);
-            for (int y = 0; y < 5; y++)
-                for (int x = 0; x < 5; x++) a[x + 5 * y] = b[x + 5 * y] ^ (~b[(x + 1) % 5 + 5 * y] & b[(x + 2) % 5 + 5 * y]);
-            a[0] ^= rc[round];
+    constexpr KeccakWalk W = keccak_walk();
+    uint64_t s[25];
+    for (int i = 0; i < 25; i++) s[i] = a[i];
+    for (int round = 0; round < 24; round++) {
+        uint64_t c[5];
+#pragma GCC unroll 5
+        for (int x = 0; x < 5; x++) c[x] = s[x] ^ s[x + 5] ^ s[x + 10] ^ s[x + 15] ^ s[x + 20];
+#pragma GCC unroll 5
+        for (int x = 0; x < 5; x++) {
+            const uint64_t n = c[(x + 1) % 5];
+            const uint64_t d = c[(x + 4) % 5] ^ ((n << 1) | (n >> 63));
+#pragma GCC unroll 5
+            for (int y = 0; y < 25; y += 5) s[x + y] ^= d;
         }
-    };
+        uint64_t carry = s[1];                          // rho and pi along the walk that starts at lane (1, 0)
+#pragma GCC unroll 24
+        for (int t = 0; t < 24; t++) {
+            const uint64_t next = s[W.lane[t]];
+            s[W.lane[t]] = (carry << W.rot[t]) | (carry >> (64 - W.rot[t]));
+            carry = next;
+        }
+#pragma GCC unroll 5
+        for (int y = 0; y < 25; y += 5) {
+            const uint64_t b0 = s[y], b1 = s[y + 1], b2 = s[y + 2], b3 = s[y + 3], b4 = s[y + 4];
+            s[y] = b0 ^ (~b1 & b2);
+            s[y + 1] = b1 ^ (~b2 & b3);
+            s[y + 2] = b2 ^ (~b3 & b4);
+            s[y + 3] = b3 ^ (~b4 & b0);
+            s[y + 4] = b4 ^ (~b0 & b1);
+        }
+        s[0] ^= rc[round];
+    }
+    for (int i = 0; i < 25; i++) a[i] = s[i];
+}
+
+inline void shake256_into(const uint8_t* in, size_t len, uint8_t* out, size_t outlen)
+{
     const size_t rate = 136;
     uint64_t s[25] = {0};
     uint8_t* sb = reinterpret_cast<uint8_t*>(s);
     while (len >= rate) {
-        for (size_t i = 0; i < rate; i++) sb[i] ^= in[i];
-        permute(s);
+        uint64_t block[17];
+        std::memcpy(block, in, rate);
+        for (int i = 0; i < 17; i++) s[i] ^= block[i];
+        keccak_f1600(s);
         in += rate;
         len -= rate;
     }
     for (size_t i = 0; i < len; i++) sb[i] ^= in[i];
     sb[len] ^= 0x1F;
     sb[rate - 1] ^= 0x80;
-    permute(s);
-    std::vector<uint8_t> out(outlen);
+    keccak_f1600(s);
     size_t off = 0;
     while (off < outlen) {
         size_t k = outlen - off < rate ? outlen - off : rate;
-        std::memcpy(out.data() + off, sb, k);
+        std::memcpy(out + off, sb, k);
         off += k;
-        if (off < outlen) permute(s);
+        if (off < outlen) keccak_f1600(s);
     }
+}
+
+inline std::vector<uint8_t> shake256(const uint8_t* in, size_t len, size_t outlen)
+{
+    std::vector<uint8_t> out(outlen);
+    shake256_into(in, len, out.data(), outlen);
     return out;
 }
 

@@ -385,14 +385,18 @@ struct ProofStream {
     }
     static std::vector<uint8_t> bincode(const std::vector<std::string>& objs, size_t upto)
     {
-        std::vector<uint8_t> out;
+        size_t total = 8;
+        for (size_t i = 0; i < upto; i++) total += 8 + objs[i].size();
+        std::vector<uint8_t> out(total);
+        uint8_t* p = out.data();
         auto put64 = [&](uint64_t v) {
-            for (int i = 0; i < 8; i++) out.push_back((uint8_t)(v >> (8 * i)));
+            for (int i = 0; i < 8; i++) *p++ = (uint8_t)(v >> (8 * i));
         };
         put64(upto);
         for (size_t i = 0; i < upto; i++) {
             put64(objs[i].size());
-            out.insert(out.end(), objs[i].begin(), objs[i].end());
+            std::memcpy(p, objs[i].data(), objs[i].size());
+            p += objs[i].size();
         }
         return out;
     }
