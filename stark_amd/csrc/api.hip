@@ -1637,13 +1637,15 @@ extern "C" size_t stark_fri_num_rounds(size_t domain_length, size_t expansion_fa
 // power tables of omega^-1 covering exponents < N
 static int32_t fold_tables(stark_ctx* ctx, fe omega, size_t N, PowRef* out)
 {
-    return get_pow_tables(ctx, ctx->F.inverse(omega), N, false, out);
+    return get_pow_tables(ctx, ctx->F.inverse(omega), N, true, out);
 }
 
-static fe fold_constant(const HostField& F, fe alpha, fe offset)
+// the two constants of a fold (fri.rs:133-138 rearranged: out = b + (a - b)(2^-1 + c omega^-i), c = 2^-1 alpha / offset)
+static void fold_constants(const HostField& F, fe alpha, fe offset_inv, FoldArgs& a)
 {
-    fe two_inv = F.inverse(fe{2, 0});
-    return F.to_mont(F.mul(F.mul(two_inv, alpha), F.inverse(offset)));
+    static const fe two_inv = F.inverse(fe{2, 0});
+    a.c5 = to_tw5(F, F.mul(F.mul(two_inv, alpha), offset_inv));
+    a.half5 = to_tw5(F, two_inv);
 }
 
 extern "C" int32_t stark_fri_fold_dev(stark_ctx* ctx, const uint64_t* codeword_dev, size_t N,
@@ -1661,9 +1663,9 @@ extern "C" int32_t stark_fri_fold_dev(stark_ctx* ctx, const uint64_t* codeword_d
     a.cw = (const fe*)codeword_dev;
     a.out = (fe*)out_dev;
     a.leaf_out = nullptr;
-    a.hi = (const fe*)pt->hi;
-    a.lo = (const fe*)pt->lo;
-    a.c_m = fold_constant(ctx->F, al, of);
+    a.hi = (const tw5*)pt->hi;
+    a.lo = (const tw5*)pt->lo;
+    fold_constants(ctx->F, al, ctx->F.inverse(of), a);
     a.half = N / 2;
     a.shift = 0;
     HIP_TRY(launch_fri_fold(a, ctx->stream));
@@ -1694,9 +1696,9 @@ extern "C" int32_t stark_fri_fold_shard_dev(stark_ctx* ctx, const uint64_t* loca
     a.cw = (const fe*)local_dev;
     a.out = (fe*)out_dev;
     a.leaf_out = nullptr;
-    a.hi = (const fe*)pt->hi;
-    a.lo = (const fe*)pt->lo;
-    a.c_m = fold_constant(ctx->F, al, of);
+    a.hi = (const tw5*)pt->hi;
+    a.lo = (const tw5*)pt->lo;
+    fold_constants(ctx->F, al, ctx->F.inverse(of), a);
     a.half = half;
     a.shift = 0;
     a.log_chunk = (uint32_t)log_chunk;
@@ -1822,7 +1824,6 @@ static int32_t fri_commit_impl(stark_ctx* ctx, const fe* cw_src, bool src_is_hos
     }
     // 2^-1 alpha offset_r^-1 per round: the two inverses are taken once (a Fermat inverse is ~400
     // host multiplications) and offset_r^-1 = (offset^-1)^(2^r) follows by squaring (fri.rs:142)
-    const fe two_inv = F.inverse(fe{2, 0});
     fe offset_inv_r = F.inverse(of);
     for (size_t r = 0; r < rounds; r++) {
         const size_t n = L->len[r];
@@ -1841,9 +1842,9 @@ static int32_t fri_commit_impl(stark_ctx* ctx, const fe* cw_src, bool src_is_hos
         a.cw = L->cw[r];
         a.out = L->cw[r + 1];
         a.leaf_out = L->tree[r + 1];
-        a.hi = (const fe*)pt->hi;
-        a.lo = (const fe*)pt->lo;
-        a.c_m = F.to_mont(F.mul(F.mul(two_inv, alpha), offset_inv_r));
+        a.hi = (const tw5*)pt->hi;
+        a.lo = (const tw5*)pt->lo;
+        fold_constants(F, alpha, offset_inv_r, a);
         a.half = n / 2;
         a.shift = (uint32_t)r;
         FRI_HIP(launch_fri_fold_commit(a, ctx->stream, root_mail));                                   // fri.rs:133-139,119

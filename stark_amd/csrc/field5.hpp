@@ -21,6 +21,7 @@
 // result nearly canonical whatever the laziness of a.  Twiddles are stored as
 // w*2^156 mod p (struct tw5).  pack_canonical() finishes the reduction.
 #pragma once
+#include <math.h>
 #include <stdint.h>
 
 #include "field.hpp"
@@ -400,6 +401,33 @@ STARK_HD fe pack_canonical(const fe5& r)
 {
     if (noncanonical5(r)) return reduce5_slow(r);
     return pack_fast(r);
+}
+
+// Any lazy limb vector with |value| < 2^134 (sums of a few products and canonical values) -> canonical
+// 128 bits, without a multiplication: q ~ floor(value / p) from the two top limbs,
+// value - q*p = (L - q) + (top - q*P4) * 2^104, one carry sweep, and the exact slow path whenever the top
+// digit does not land in [0, P4) (q off by one, or value = p - 1).
+STARK_HD fe finish_lazy(const fe5& x)
+{
+    const int32_t d_top = x.l[4] + (x.l[3] >> LIMB_BITS);
+    const int32_t q = (int32_t)floorf((float)d_top * (1.0f / (float)P4));
+    fe5 r;
+    int32_t c = x.l[0] - q;
+    r.l[0] = c & LIMB_MASK;
+    c >>= LIMB_BITS;
+    c += x.l[1];
+    r.l[1] = c & LIMB_MASK;
+    c >>= LIMB_BITS;
+    c += x.l[2];
+    r.l[2] = c & LIMB_MASK;
+    c >>= LIMB_BITS;
+    c += x.l[3];
+    r.l[3] = c & LIMB_MASK;
+    c >>= LIMB_BITS;
+    r.l[4] = c + x.l[4] - q * P4;
+    fe o = pack_fast(r);
+    if (__builtin_expect((uint32_t)r.l[4] >= (uint32_t)P4, 0)) o = reduce5_slow(x);
+    return o;
 }
 
 }  // namespace starkf

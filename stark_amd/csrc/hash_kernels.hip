@@ -499,18 +499,25 @@ hipError_t launch_merkle_reduce(digest* level, size_t m, hipStream_t s, digest* 
 // omega^-i comes from the hi/lo power tables of the top-level root w
 // (omega = w^(2^shift)); optionally the leaf digest of out[i] is produced in
 // the same pass so the next layer's codeword is not re-read for hashing.
+// With u = 2^-1 + c omega^-i the two weights are u and 1 - u, so out[i] = b + (a - b) u: the sum and
+// the halving disappear, and on the lazy five-limb core the three products (table entries, constant,
+// difference) cost half of what they do on 64-bit words; the one reduction is that of the result.
 __device__ __forceinline__ fe fold_one(const FoldArgs& a, size_t i)
 {
-    fe x = a.cw[i], y = a.cw[a.half + i];
-    fe sum = fe_half(fe_add(x, y));
-    fe dif = fe_sub(x, y);
+    const fe x = a.cw[i], y = a.cw[a.half + i];
     const uint64_t pos = (((uint64_t)i >> a.log_chunk) << a.log_period) + a.base + ((uint64_t)i & ((1ull << a.log_chunk) - 1));
     const uint64_t E = pos << a.shift;
-    fe w = a.hi[E >> 8];
-    const uint32_t el = (uint32_t)(E & 255);
-    if (el) w = mont_mul(w, a.lo[el]);
-    w = mont_mul(w, a.c_m);
-    return fe_add(sum, mont_mul(dif, w));
+    auto limbs = [](const tw5& t) {
+        fe5 r;
+#pragma unroll
+        for (int l = 0; l < 5; l++) r.l[l] = t.l[l];
+        return r;
+    };
+    fe5 w = limbs(a.hi[E >> 8]);
+    if (a.shift < 8) w = mont_mul5(w, a.lo[E & 255]);          // (from layer 8 on the low exponent bits are zero)
+    const fe5 u = add5(mont_mul5(w, a.c5), limbs(a.half5));
+    const fe5 yb = unpack5(y);
+    return finish_lazy(add5(yb, mont_mul5(sub5(unpack5(x), yb), u)));
 }
 
 template <bool LEAF>

@@ -120,9 +120,10 @@ struct FoldArgs {
     const fe* cw;          // N elements
     fe* out;               // N/2 elements
     digest* leaf_out;      // optional: leaf digests of out (level 0 of its tree)
-    const fe* hi;          // w^-(i << 8), Montgomery form
-    const fe* lo;          // w^-i, i<256, Montgomery form
-    fe c_m;                // 2^-1 * alpha * offset^-1, Montgomery form
+    const tw5* hi;         // w^-(i << 8), five-limb Montgomery form
+    const tw5* lo;         // w^-i, i<256, five-limb Montgomery form
+    tw5 c5;                // 2^-1 * alpha * offset^-1, five-limb Montgomery form
+    tw5 half5;             // 2^-1, five-limb Montgomery form
     uint64_t half;         // N/2
     uint32_t shift;        // omega of this layer = w^(2^shift)
     // Position of local element l in the whole layer: ((l >> log_chunk) << log_period) + base +

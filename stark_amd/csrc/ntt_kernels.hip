@@ -108,33 +108,8 @@ __device__ __forceinline__ void lds_barrier()
 
 // lazy element -> canonical 128-bit value (the slow path is rare: it is taken
 // when the reduced value came out as p + small or small negative)
-// Any lazy limb vector with |value| < 2^134 (the sums of up to sixteen products that leave the last
-// pass's butterflies) -> canonical 128 bits, without a multiplication: q ~ floor(value / p) from the
-// two top limbs, value - q*p = (L - q) + (top - q*P4) * 2^104, one carry sweep, and the exact slow
-// path whenever the top digit does not land in [0, P4) (q off by one, or value = p - 1).
-__device__ __forceinline__ fe finish_lazy(const fe5& x)
-{
-    const int32_t d_top = x.l[4] + (x.l[3] >> LIMB_BITS);
-    const int32_t q = (int32_t)floorf((float)d_top * (1.0f / (float)P4));
-    fe5 r;
-    int32_t c = x.l[0] - q;
-    r.l[0] = c & LIMB_MASK;
-    c >>= LIMB_BITS;
-    c += x.l[1];
-    r.l[1] = c & LIMB_MASK;
-    c >>= LIMB_BITS;
-    c += x.l[2];
-    r.l[2] = c & LIMB_MASK;
-    c >>= LIMB_BITS;
-    c += x.l[3];
-    r.l[3] = c & LIMB_MASK;
-    c >>= LIMB_BITS;
-    r.l[4] = c + x.l[4] - q * P4;
-    fe o = pack_fast(r);
-    if (__builtin_expect((uint32_t)r.l[4] >= (uint32_t)P4, 0)) o = reduce5_slow(x);
-    return o;
-}
-
+// (the sums of up to sixteen products that leave the last pass's butterflies go through finish_lazy of
+// field5.hpp instead)
 __device__ __forceinline__ fe finish(const fe5& x)
 {
     fe o = pack_fast(x);
