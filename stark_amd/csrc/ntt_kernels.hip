@@ -110,10 +110,18 @@ __device__ __forceinline__ void lds_barrier()
 // when the reduced value came out as p + small or small negative)
 // (the sums of up to sixteen products that leave the last pass's butterflies go through finish_lazy of
 // field5.hpp instead)
+// The test is taken for the whole wave at once (two compares into scalar masks and a scalar branch): the
+// per-lane form costs five vector instructions and an exec-mask round trip per element for a path that a
+// wave takes about once in 2^14 elements.
 __device__ __forceinline__ fe finish(const fe5& x)
 {
     fe o = pack_fast(x);
-    if (__builtin_expect(noncanonical5(x) != 0, 0)) o = reduce5_slow(x);
+    constexpr int UGT = 34, UGE = 35;                          // unsigned >, >= (LLVM's integer predicates)
+    const uint64_t some = __builtin_amdgcn_uicmp((uint32_t)x.l[0], (uint32_t)LIMB_MASK, UGT) |
+                          __builtin_amdgcn_uicmp((uint32_t)x.l[4], (uint32_t)P4, UGE);
+    if (__builtin_expect(some != 0, 0)) {
+        if (noncanonical5(x)) o = reduce5_slow(x);
+    }
     return o;
 }
 
@@ -148,6 +156,44 @@ __device__ __forceinline__ uint64_t last_pass_column(const PassArgs& a, uint64_t
     else return b;
 }
 
+// A lane's fixed offset, handed out afresh for every access: if the compiler could see that it is the same
+// value each time it would add it to the base once and then form "(base + lane offset) + rows" on the vector
+// pipes for every access, instead of "(base + rows)" on the scalar unit plus the offset operand of the access.
+__device__ __forceinline__ uint32_t lane_offset(uint32_t x)
+{
+    asm volatile("" : "+v"(x));
+    return x;
+}
+
+// Where a tile of a strided pass (first or middle, transforms of at least 4096 points) sits: the element
+// index of its column 0, row 0, which is the same for the whole workgroup and stays in scalar registers,
+// and this lane's distance from it in elements (column c of the tile, row `row` of the sub-transform).
+// A lane is never more than 16 rows and one tile of columns away, so its distance fits 32 bits even in
+// bytes (log_s <= 24, checked at launch), and an access is "uniform pointer + 32-bit lane offset": the
+// form a global load or store takes with its base in scalar registers, with no address arithmetic on the
+// vector pipes per access.
+struct TileOrigin {
+    uint64_t batch;      // which transform of the batch
+    uint64_t elem;       // element index of (column 0, row 0) inside that transform
+};
+template <int RA>
+__device__ __forceinline__ TileOrigin tile_origin(const PassArgs& a, uint64_t tile)
+{
+    TileOrigin o;
+    uint64_t f0;
+    locate<RA, false>(a, tile, 0, o.batch, f0);
+    o.elem = ((f0 >> a.log_s) << (a.r + a.log_s)) + (f0 & (((uint64_t)1 << a.log_s) - 1));
+    return o;
+}
+template <int RA>
+__device__ __forceinline__ uint32_t lane_distance(const PassArgs& a, uint64_t tile, const TileOrigin& o, int c, int row)
+{
+    uint64_t batch, f;
+    locate<RA, false>(a, tile, c, batch, f);
+    const uint64_t base = ((f >> a.log_s) << (a.r + a.log_s)) + (f & (((uint64_t)1 << a.log_s) - 1));
+    return (uint32_t)(base - o.elem) + ((uint32_t)row << a.log_s);
+}
+
 // Issue the 16 global loads of one thread for one tile (round-1 layout).
 // tile enumerates (batch, tile-in-transform); rows past n_src of a first pass
 // are the zero padding and are not read.
@@ -175,6 +221,26 @@ __device__ __forceinline__ void load_tile(fe (&raw)[16], const PassArgs& a, uint
                     if (batch < a.n_batch) raw[g * M1 + ja] = src[row + ja * 16 + jb];
                 } else {
                     raw[g * M1 + ja] = src[row + ja * 16 + jb];
+                }
+            }
+        } else if constexpr (!SMALL) {
+            const int jb = q1 >> LOGC, c = q1 & (C - 1);
+            const TileOrigin o = tile_origin<RA>(a, tile);
+            const uint32_t lane_el = lane_distance<RA>(a, tile, o, c, jb);
+            const char* __restrict__ src = (const char*)(a.src + o.batch * a.src_batch_stride + o.elem);
+#pragma unroll
+            for (int ja = 0; ja < M1; ja++) {
+                const uint64_t rows = (uint64_t)(ja * 16) << a.log_s;              // the same for every lane
+                const fe* __restrict__ p = (const fe*)(src + rows * sizeof(fe) + lane_offset(lane_el * (uint32_t)sizeof(fe)));
+                if constexpr (MODE == PASS_FIRST) {
+                    // valid while origin + rows + lane_el < n_src: the bound on lane_el is the same for every lane
+                    const uint64_t before = o.elem + rows;
+                    const uint64_t room = a.n_src > before ? a.n_src - before : 0;
+                    const uint32_t limit = room > 0xffffffffull ? 0xffffffffu : (uint32_t)room;
+                    raw[g * M1 + ja] = fe_zero();
+                    if (lane_el < limit) raw[g * M1 + ja] = *p;
+                } else {
+                    raw[g * M1 + ja] = *p;
                 }
             }
         } else {
@@ -337,14 +403,109 @@ __device__ __forceinline__ void round2_store(fe5 (&v)[16], const PassArgs& a, ui
         ntt_dif_reg<4, 0, false>(v);
         const uint64_t b = last_pass_column<INV>(a, f);
         const uint32_t sh = a.log_n - a.r;
+        if constexpr (!SMALL) {
+            // Output kb goes to index ((ka2 + M1 kb) << sh) + b: this lane's part (ka2 << sh) + b is below
+            // n / 16 + n / R, the rest is the same for every lane, so a store is a scalar base plus a fixed
+            // 32-bit lane offset.  Reversed (INV), index i becomes n - i: the lane part is counted down from a
+            // bound above it, M1 << sh, which leaves the scalar part n - ((M1 (kb + 1)) << sh) >= 0; index 0
+            // stays index 0 and can only be output 0 of a thread.
+            char* __restrict__ out = (char*)dst;
+            const uint32_t lane_el = ((uint32_t)ka2 << sh) + (uint32_t)b;
+            const uint32_t lane_b = (INV ? ((uint32_t)M1 << sh) - lane_el : lane_el) * (uint32_t)sizeof(fe);
 #pragma unroll
-        for (int kb = 0; kb < 16; kb++) {
-            uint32_t k = ka2 + M1 * kb;
-            asm volatile("" : "+v"(k));
-            const fe o = finish_lazy(v[brev_c(kb, 4)]);
-            uint64_t idx = ((uint64_t)k << sh) + b;
-            if constexpr (INV) idx = (0 - idx) & (((uint64_t)1 << a.log_n) - 1);
-            if (live) dst[idx] = o;
+            for (int kb = 0; kb < 16; kb++) {
+                const fe o16 = finish_lazy(v[brev_c(kb, 4)]);
+                if constexpr (!INV) {
+                    *(fe*)(out + (((uint64_t)(M1 * kb) << sh) * sizeof(fe)) + lane_offset(lane_b)) = o16;
+                } else if (kb == 0) {
+                    dst[(0 - (uint64_t)lane_el) & (((uint64_t)1 << a.log_n) - 1)] = o16;
+                } else {
+                    const uint64_t top = ((uint64_t)1 << a.log_n) - ((uint64_t)(M1 * (kb + 1)) << sh);
+                    *(fe*)(out + top * sizeof(fe) + lane_offset(lane_b)) = o16;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int kb = 0; kb < 16; kb++) {
+                uint32_t k = ka2 + M1 * kb;
+                asm volatile("" : "+v"(k));
+                const fe o = finish_lazy(v[brev_c(kb, 4)]);
+                uint64_t idx = ((uint64_t)k << sh) + b;
+                if constexpr (INV) idx = (0 - idx) & (((uint64_t)1 << a.log_n) - 1);
+                if (live) dst[idx] = o;
+            }
+        }
+    } else if constexpr (!SMALL && NEXT_LAST != 1) {
+        // Output kb of this thread is element origin + lane_el + ((M1 kb) << log_s) of the transform: the last
+        // term is the same for every lane, so the store (and the plane load next to it) is a scalar base plus
+        // this lane's fixed 32-bit offset, and the exponent of a tabulated twiddle advances by a fixed step.
+        const TileOrigin o = tile_origin<RA>(a, tile);
+        const uint32_t lane_el = lane_distance<RA>(a, tile, o, c2, ka2);
+        const uint32_t lane_b = lane_el * (uint32_t)sizeof(fe);
+        char* __restrict__ out = (char*)(a.dst + o.batch * a.dst_batch_stride + o.elem);
+        auto rows_of = [&](int kb) { return ((uint64_t)(M1 * kb) << a.log_s); };
+        if constexpr (NEXT_LAST == 2) {
+            // the twiddle of output element i comes ready-made from the plane: a 20-byte load
+            // next to the store instead of two gathers and a multiplication
+            const char* __restrict__ plane = (const char*)(a.plane + 5 * o.elem);
+            const uint32_t lane_p = lane_el * 20u;
+            fe5 w[2];
+            auto issue = [&](int kb) { w[kb & 1] = *(const fe5*)(plane + rows_of(kb) * 20 + lane_offset(lane_p)); };
+            ntt_dif_reg<4, 0, false>(v);
+            issue(0);
+#pragma clang loop unroll(full)
+            for (int kb = 0; kb < 16; kb++) {
+                if (kb + 1 < 16) issue(kb + 1);
+                const fe o16 = finish(mont_mul5_v(v[brev_c(kb, 4)], w[kb & 1]));
+                *(fe*)(out + rows_of(kb) * sizeof(fe) + lane_offset(lane_b)) = o16;
+            }
+        } else if constexpr (NEXT_LAST == 3) {
+            // the same from the plane of canonical 16-byte values
+            const char* __restrict__ plane16 = (const char*)(a.plane16 + o.elem);
+            fe w[2];
+            auto issue = [&](int kb) { w[kb & 1] = *(const fe*)(plane16 + rows_of(kb) * sizeof(fe) + lane_offset(lane_b)); };
+            ntt_dif_reg<4, 0, false>(v);
+            issue(0);
+#pragma clang loop unroll(full)
+            for (int kb = 0; kb < 16; kb++) {
+                if (kb + 1 < 16) issue(kb + 1);
+                const fe o16 = finish(mont_mul5_v(v[brev_c(kb, 4)], unpack5(w[kb & 1])));
+                *(fe*)(out + rows_of(kb) * sizeof(fe) + lane_offset(lane_b)) = o16;
+            }
+        } else {
+            // twiddle of the next pass from the hi table: w_n^(j_next * K * S_next), K = K_prev + k * 2^bits_prev,
+            // k = ka2 + M1 kb: the exponent of output kb is that of output 0 plus kb fixed steps
+            const uint32_t pre = (uint32_t)(f >> a.log_s);
+            const uint32_t col = (uint32_t)(f & (((uint64_t)1 << a.log_s) - 1));
+            const uint32_t j_next = col >> a.log_s_next;
+            uint32_t bits_prev = 0;
+            for (uint32_t u = 0; u < a.nprev; u++) bits_prev += a.rprev[u];
+            const uint32_t k_prev = prefix_to_k(pre, a);
+            const uint32_t sn = a.log_s_next - a.h;                // S_next / 2^h
+            const char* __restrict__ hi = (const char*)a.hi;
+            uint32_t e_b = ((j_next * (k_prev + ((uint32_t)ka2 << bits_prev))) << sn) * (uint32_t)sizeof(tw5);
+            const uint32_t step_b = ((j_next * ((uint32_t)M1 << bits_prev)) << sn) * (uint32_t)sizeof(tw5);
+            constexpr int B = 2;
+            tw5 w[2][B];
+            auto issue = [&](int bt) {
+#pragma clang loop unroll(full)
+                for (int i = 0; i < B; i++) {
+                    w[bt & 1][i] = *(const tw5*)(hi + e_b);
+                    e_b += step_b;
+                }
+            };
+            issue(0);
+            ntt_dif_reg<4, 0, false>(v);
+#pragma clang loop unroll(full)
+            for (int bt = 0; bt < 16 / B; bt++) {
+                if (bt + 1 < 16 / B) issue(bt + 1);
+#pragma clang loop unroll(full)
+                for (int i = 0; i < B; i++) {
+                    const int kb = bt * B + i;
+                    const fe o16 = finish(mont_mul5_v(v[brev_c(kb, 4)], w[bt & 1][i]));
+                    *(fe*)(out + rows_of(kb) * sizeof(fe) + lane_offset(lane_b)) = o16;
+                }
+            }
         }
     } else {
         const uint32_t pre = (uint32_t)(f >> a.log_s);
@@ -609,6 +770,8 @@ static hipError_t launch_ra(const PassArgs& a, PassMode mode, bool twist, hipStr
 hipError_t launch_ntt_pass(const PassArgs& a_in, PassMode mode, bool twist, uint32_t n_batch, hipStream_t s)
 {
     if (a_in.log_n < (uint32_t)SHORT_MIN_LOG || a_in.log_n > 30 || a_in.r > a_in.log_n) return hipErrorInvalidValue;
+    // the kernels address a tile as a scalar base plus 32-bit lane offsets of up to 16 rows (tile_origin)
+    if (mode != PASS_LAST && a_in.log_s > 24) return hipErrorInvalidValue;
     PassArgs a = a_in;
     a.n_batch = n_batch;
     if (a.log_n < 12) {                                        // several transforms share a 4096-element tile
