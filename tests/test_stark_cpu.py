@@ -300,3 +300,31 @@ def test_reference_polynomial_known_answers(hm):
     rem = sp.poly_sub([3, 2, 1], sp.poly_mul(q, [1, 1]))
     assert sp.poly_add(sp.poly_mul(q, [1, 1]), rem) == [3, 2, 1] and q == [3, P - 1]
     assert so.test_colinearity([(0, 0), (1, 1), (2, 2)])                            # test_test_colinearity
+
+
+# --- proof_stream.rs: the transcript's hash ---------------------------------------------
+def test_mirror_shake256_vs_hashlib(hm):
+    """SHAKE256 of the mirror (proof_stream.rs:52,63: sha3::Shake256) against hashlib: message lengths on both sides
+    of the 136-byte rate, several blocks, and outputs longer than one block."""
+    import hashlib
+    lib = hm.lib
+    rnd = random.Random(202)
+    for n in (0, 1, 7, 8, 135, 136, 137, 271, 272, 273, 1000, 1360, 4097):
+        data = bytes(rnd.randrange(256) for _ in range(n))
+        for outlen in (1, 32, 135, 136, 137, 300):
+            out = (C.c_uint8 * outlen)()
+            lib.sh_shake256(data, C.c_size_t(n), out, C.c_size_t(outlen))
+            assert bytes(out) == hashlib.shake_256(data).digest(outlen), (n, outlen)
+
+
+def test_mirror_fiat_shamir_is_shake256_of_the_serialised_stream(hm):
+    """prover_fiat_shamir (proof_stream.rs:50-58) over a stream that grows by one object a round, as in Fri::commit."""
+    import hashlib
+    ps = hm.Stream()
+    objs = []
+    for r in range(20):
+        objs.append("%064x" % (r * 0x9E3779B97F4A7C15))
+        ps.push(objs[-1])
+        ser = len(objs).to_bytes(8, "little") + b"".join(len(o).to_bytes(8, "little") + o.encode() for o in objs)
+        assert bytes(ps.serialize()) == ser
+        assert bytes(ps.fiat_shamir(32)) == hashlib.shake_256(ser).digest(32)

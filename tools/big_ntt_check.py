@@ -13,7 +13,7 @@ for log_n in (25, 26):
     b = ctx.ntt(f, inverse=True)
     print(log_n, 'roundtrip', np.array_equal(b, x), flush=True)
     del ref, f, b
-for log_n in (27, 28):
+for log_n in (27, 28, 30):
     n = 1 << log_n
     x = oc.splitmix(n, log_n)
     d = torch.from_numpy(x.view(np.int64)).cuda()
