@@ -109,8 +109,13 @@ struct stark_ctx {
     uint64_t pow_clock = 0;
     fe* scratch = nullptr;
     size_t scratch_elems = 0;
-    std::multimap<size_t, void*> pool;                 // cached device blocks by size
+    struct PoolBlock {
+        void* p;
+        uint64_t stamp;                                // when it was released (pool_clock)
+    };
+    std::multimap<size_t, PoolBlock> pool;             // cached device blocks by size
     size_t pool_large_bytes = 0;                       // bytes of the cached blocks of at least 1 MiB
+    uint64_t pool_clock = 0;
     std::map<void*, size_t> dev_blocks;                // blocks handed out by stark_dev_alloc, by address
     void* pinned = nullptr;                            // small pinned staging buffer (4 KiB)
     void* pin_io = nullptr;                            // 2 x 64 KiB host-mapped: small transforms run on it in place
@@ -208,7 +213,7 @@ constexpr size_t POOL_MAX_LARGE_BYTES = (size_t)8 << 30;
 
 static void pool_drop(stark_ctx* ctx)
 {
-    for (auto& kv : ctx->pool) (void)hipFree(kv.second);
+    for (auto& kv : ctx->pool) (void)hipFree(kv.second.p);
     ctx->pool.clear();
     ctx->pool_large_bytes = 0;
 }
@@ -230,7 +235,7 @@ static int32_t pool_alloc(stark_ctx* ctx, size_t bytes, void** out)
     bytes = pool_bucket(bytes);
     auto it = ctx->pool.find(bytes);
     if (it != ctx->pool.end()) {
-        *out = it->second;
+        *out = it->second.p;
         ctx->pool.erase(it);
         if (bytes >= POOL_LARGE) ctx->pool_large_bytes -= bytes;
         return STARK_OK;
@@ -247,15 +252,31 @@ static void pool_free(stark_ctx* ctx, void* p, size_t bytes)
     // keep at most a handful of large blocks, bounded in bytes too, and a few hundred small ones
     bool keep = ctx->pool.size() < 512;
     if (keep && bytes >= POOL_LARGE) {
-        size_t large = 0;
-        for (auto& kv : ctx->pool) large += kv.first >= POOL_LARGE;
-        keep = large < POOL_MAX_LARGE_BLOCKS && ctx->pool_large_bytes + bytes <= POOL_MAX_LARGE_BYTES;
+        // The block just released is the likeliest to be asked for again (a loop of calls of one size), so
+        // when the cache is full it is the blocks released longest ago that go, not this one: a cache that
+        // refuses the new block instead makes every later call of that size pay a hipMalloc and a hipFree
+        // (6 ms per call at 64 MiB once a 2^24 FRI commit's arenas had filled it).
+        keep = bytes <= POOL_MAX_LARGE_BYTES;
+        while (keep) {
+            size_t large = 0;
+            auto oldest = ctx->pool.end();
+            for (auto it = ctx->pool.begin(); it != ctx->pool.end(); ++it) {
+                if (it->first < POOL_LARGE) continue;
+                large++;
+                if (oldest == ctx->pool.end() || it->second.stamp < oldest->second.stamp) oldest = it;
+            }
+            if (large < POOL_MAX_LARGE_BLOCKS && ctx->pool_large_bytes + bytes <= POOL_MAX_LARGE_BYTES) break;
+            if (oldest == ctx->pool.end()) break;
+            (void)hipFree(oldest->second.p);
+            ctx->pool_large_bytes -= oldest->first;
+            ctx->pool.erase(oldest);
+        }
     }
     if (!keep) {
         (void)hipFree(p);
         return;
     }
-    ctx->pool.emplace(bytes, p);
+    ctx->pool.emplace(bytes, stark_ctx::PoolBlock{p, ++ctx->pool_clock});
     if (bytes >= POOL_LARGE) ctx->pool_large_bytes += bytes;
 }
 
