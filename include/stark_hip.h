@@ -66,8 +66,9 @@ int32_t stark_ctx_set_stream(stark_ctx* ctx, void* hip_stream);
 int32_t stark_ctx_reset_stream(stark_ctx* ctx);
 int32_t stark_ctx_synchronize(stark_ctx* ctx);
 /* Releases the device memory a context keeps between calls for speed (cached
- * scratch blocks of up to 8 GiB in total, the transform's ping buffer, twiddle
- * tables and planes); everything is rebuilt on next use.  When an allocation
+ * scratch blocks of up to 8 GiB in total -- when that is reached the blocks
+ * released longest ago make room for the one just released --, the transform's
+ * ping buffer, twiddle tables and planes); everything is rebuilt on next use.  When an allocation
  * fails the library gives the cached scratch blocks back by itself and tries
  * once more before it reports STARK_ENOMEM; the ping buffer, tables and planes
  * are only released by this call. */
