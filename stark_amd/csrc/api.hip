@@ -2024,17 +2024,22 @@ extern "C" int32_t stark_fri_query_all(stark_fri_layers* l, const uint64_t* top_
     for (size_t i = 0; i < count; i++)
         if (top_indices[i] >= l->len[0]) return fail(STARK_EINDEX, "cannot open invalid index");
     stark_ctx* ctx = l->ctx;
-    // one staging block for all rounds: [indices | values | paths]; one copy in, the launches of every
-    // round back to back, two copies out, one synchronisation
+    // one staging block for all rounds: [round table | indices | values | paths]; one copy in, ONE launch that
+    // answers every opening of every round, two copies out, one synchronisation
+    static_assert(sizeof(QueryRound) % sizeof(uint64_t) == 0, "the round table precedes the 64-bit indices");
+    const size_t tab_words = rounds * (sizeof(QueryRound) / sizeof(uint64_t));
+    const size_t val_bytes = rounds * 3 * count * sizeof(fe);
+    std::vector<uint64_t> in((tab_words + rounds * 3 * count + 3) / 4 * 4);       // whole 32-byte units: values and paths follow
+    QueryRound* tab = (QueryRound*)in.data();
     size_t path_digests = 0;
-    for (size_t r = 0; r < rounds; r++)
-        path_digests += count * (2 * (size_t)log2_exact(l->len[r]) + (size_t)log2_exact(l->len[r + 1]));
-    const size_t idx_bytes = rounds * 3 * count * sizeof(uint64_t), val_bytes = rounds * 3 * count * sizeof(fe);
-    std::vector<uint64_t> idx(rounds * 3 * count);
     for (size_t r = 0; r < rounds; r++) {
-        const size_t half = l->len[r] / 2;
-        if (l->len[r + 1] < half) return fail(STARK_ELENGTH, "a layer is shorter than half of the one before");
-        uint64_t* ir = idx.data() + r * 3 * count;
+        const size_t n = l->len[r], n_next = l->len[r + 1], half = n / 2;
+        if (n_next < half) return fail(STARK_ELENGTH, "a layer is shorter than half of the one before");
+        const int depth = log2_exact(n), depth_next = log2_exact(n_next);
+        tab[r] = QueryRound{l->cw[r], l->cw[r + 1], l->tree[r], l->tree[r + 1], n, n_next, path_digests,
+                            (uint32_t)depth, (uint32_t)depth_next};
+        path_digests += count * (2 * (size_t)depth + (size_t)depth_next);
+        uint64_t* ir = in.data() + tab_words + r * 3 * count;
         for (size_t i = 0; i < count; i++) {
             const uint64_t c = top_indices[i] % half;
             ir[i] = c;                           // a
@@ -2042,26 +2047,15 @@ extern "C" int32_t stark_fri_query_all(stark_fri_layers* l, const uint64_t* top_
             ir[2 * count + i] = c;               // c, in the next layer
         }
     }
+    const size_t in_bytes = in.size() * sizeof(uint64_t);
     DevBuf stage(ctx);
-    ST_TRY(stage.alloc(idx_bytes + val_bytes + path_digests * sizeof(digest) + 64));
-    uint64_t* d_idx = (uint64_t*)stage.p;
-    fe* d_val = (fe*)((uint8_t*)stage.p + idx_bytes);
-    digest* d_path = (digest*)((uint8_t*)stage.p + idx_bytes + val_bytes);
-    HIP_TRY(hipMemcpyAsync(d_idx, idx.data(), idx_bytes, hipMemcpyHostToDevice, ctx->stream));
-    size_t at = 0;
-    for (size_t r = 0; r < rounds; r++) {
-        const size_t n = l->len[r], n_next = l->len[r + 1];
-        const int depth = log2_exact(n), depth_next = log2_exact(n_next);
-        const uint64_t* ir = d_idx + r * 3 * count;
-        fe* vr = d_val + r * 3 * count;
-        HIP_TRY(launch_gather_fe(l->cw[r], ir, vr, 2 * count, ctx->stream));
-        HIP_TRY(launch_gather_fe(l->cw[r + 1], ir + 2 * count, vr + 2 * count, count, ctx->stream));
-        HIP_TRY(launch_merkle_open_many(l->tree[r], n, ir, 2 * count, (uint32_t)depth, d_path + at, ctx->stream));
-        at += 2 * count * (size_t)depth;
-        HIP_TRY(launch_merkle_open_many(l->tree[r + 1], n_next, ir + 2 * count, count, (uint32_t)depth_next, d_path + at,
-                                        ctx->stream));
-        at += count * (size_t)depth_next;
-    }
+    ST_TRY(stage.alloc(in_bytes + val_bytes + path_digests * sizeof(digest) + 64));
+    const QueryRound* d_tab = (const QueryRound*)stage.p;
+    const uint64_t* d_idx = (const uint64_t*)stage.p + tab_words;
+    fe* d_val = (fe*)((uint8_t*)stage.p + in_bytes);
+    digest* d_path = (digest*)((uint8_t*)stage.p + in_bytes + val_bytes);
+    HIP_TRY(hipMemcpyAsync(stage.p, in.data(), in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(launch_fri_query_all(d_tab, rounds, d_idx, count, d_val, d_path, ctx->stream));
     HIP_TRY(hipMemcpyAsync(values_out, d_val, val_bytes, hipMemcpyDeviceToHost, ctx->stream));
     if (path_digests)
         HIP_TRY(hipMemcpyAsync(paths_out, d_path, path_digests * sizeof(digest), hipMemcpyDeviceToHost, ctx->stream));

@@ -662,6 +662,37 @@ hipError_t launch_merkle_open_many(const digest* tree, size_t n, const uint64_t*
     return hipGetLastError();
 }
 
+// The whole query phase of Fri::prove (fri.rs:155-209,228-242) in one launch: block (s, r) answers opening s
+// of round r -- s < count: position a of layer r, s < 2 count: position b, else position c of layer r + 1 --
+// thread 0 fetches the element, thread k the sibling on level k of that layer's tree.
+__global__ __launch_bounds__(64) void fri_query_all_kernel(const QueryRound* __restrict__ rounds,
+                                                           const uint64_t* __restrict__ idx, uint32_t count,
+                                                           fe* __restrict__ values, digest* __restrict__ paths)
+{
+    const uint32_t s = blockIdx.x, r = blockIdx.y, k = threadIdx.x;
+    const QueryRound q = rounds[r];
+    const bool next = s >= 2 * count;
+    const size_t index = idx[(size_t)r * 3 * count + s];
+    const size_t n = next ? q.n_next : q.n;
+    const uint32_t levels = next ? q.depth_next : q.depth;
+    if (k == 0) values[(size_t)r * 3 * count + s] = (next ? q.cw_next : q.cw)[index];
+    if (k >= levels) return;
+    const digest* __restrict__ tree = next ? q.tree_next : q.tree;
+    const size_t at = next ? q.path_at + 2 * (size_t)count * q.depth + (size_t)(s - 2 * count) * q.depth_next
+                           : q.path_at + (size_t)s * q.depth;
+    paths[at + k] = tree[2 * n - ((2 * n) >> k) + ((index >> k) ^ 1)];       // level k starts at 2n - (2n >> k)
+}
+
+hipError_t launch_fri_query_all(const QueryRound* rounds_dev, size_t n_rounds, const uint64_t* idx_dev, size_t count,
+                                fe* values_out, digest* paths_out, hipStream_t s)
+{
+    if (n_rounds == 0 || count == 0) return hipSuccess;
+    if (3 * count > 0x7fffffffull || n_rounds > 65535) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(fri_query_all_kernel, dim3((uint32_t)(3 * count), (uint32_t)n_rounds), dim3(64), 0, s, rounds_dev,
+                       idx_dev, (uint32_t)count, values_out, paths_out);
+    return hipGetLastError();
+}
+
 __global__ void gather_fe_kernel(const fe* __restrict__ src, const uint64_t* __restrict__ idx, fe* __restrict__ out,
                                  size_t count)
 {

@@ -136,6 +136,20 @@ struct FoldArgs {
 hipError_t launch_fri_fold(const FoldArgs& a, hipStream_t s);
 hipError_t launch_fri_fold_commit(const FoldArgs& a, hipStream_t s, digest* root_out);
 
+// One round of the query phase as the device sees it (launch_fri_query_all): layer r and layer r + 1 with their
+// trees, and where round r's paths start in the output (2 count paths of `depth` digests, then count of `depth_next`).
+struct QueryRound {
+    const fe* cw;
+    const fe* cw_next;
+    const digest* tree;
+    const digest* tree_next;
+    uint64_t n, n_next;
+    uint64_t path_at;
+    uint32_t depth, depth_next;
+};
+hipError_t launch_fri_query_all(const QueryRound* rounds_dev, size_t n_rounds, const uint64_t* idx_dev, size_t count,
+                                fe* values_out, digest* paths_out, hipStream_t s);
+
 // Authentication path of `index` (merkle.rs:54-93): depth digests, sibling leaf first.
 // (only the lowest max_levels siblings if that is less than the depth)
 hipError_t launch_merkle_open(const digest* tree, size_t n, size_t index, digest* path_out, hipStream_t s,

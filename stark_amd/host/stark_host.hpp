@@ -101,15 +101,30 @@ struct FieldElement {
 
     std::string to_string() const                                                            // Display, field.rs:149-153
     {
-        if (value == 0) return "0";
-        std::string s;
+        // three chunks of at most 19 digits: two 128-bit divisions instead of one per digit (a FRI proof
+        // prints some nine hundred of these between its last device call and its return)
+        const u128 CH = (u128)10000000000000000000ull;                       // 10^19
+        uint64_t part[3];
         u128 v = value;
-        while (v) {
-            s.push_back((char)('0' + (int)(v % 10)));
-            v /= 10;
+        int parts = 0;
+        do {
+            part[parts++] = (uint64_t)(v % CH);
+            v /= CH;
+        } while (v);
+        char buf[64];
+        char* end = buf + sizeof(buf);
+        char* p = end;
+        for (int k = 0; k < parts; k++) {
+            uint64_t x = part[k];
+            char* chunk_end = p;
+            do {
+                *--p = (char)('0' + (int)(x % 10));
+                x /= 10;
+            } while (x);
+            if (k + 1 < parts)
+                while (chunk_end - p < 19) *--p = '0';                       // inner chunks keep their leading zeros
         }
-        std::reverse(s.begin(), s.end());
-        return s;
+        return std::string(p, (size_t)(end - p));
     }
     static FieldElement from_decimal(const std::string& s)
     {
@@ -290,7 +305,7 @@ inline std::vector<FieldElement> json_field_vec_parse(const std::string& str)   
 
 typedef std::array<uint8_t, 32> HashOutput;
 
-inline std::string json_hash_path(const std::vector<HashOutput>& path)          // fri.rs:188
+inline std::string json_hash_path_bytes(const uint8_t* digests, size_t count)    // fri.rs:188, from `count` digests back to back
 {
     // a proof carries hundreds of thousands of these bytes: a table of "0," .. "255," and one buffer
     struct Table {
@@ -309,23 +324,27 @@ inline std::string json_hash_path(const std::vector<HashOutput>& path)          
         }
     };
     static const Table T;
-    std::string s(path.size() * (32 * 4 + 2) + 2, '\0');
+    std::string s(count * (32 * 4 + 2) + 2, '\0');
     char* p = &s[0];
     *p++ = '[';
-    for (size_t i = 0; i < path.size(); i++) {
+    for (size_t i = 0; i < count; i++) {
         *p++ = '[';
         for (int b = 0; b < 32; b++) {
-            const unsigned v = path[i][b];
+            const unsigned v = digests[32 * i + b];
             std::memcpy(p, T.text[v], 4);
             p += T.len[v];
         }
         p[-1] = ']';                      // over the last comma
         *p++ = ',';
     }
-    if (!path.empty()) p--;               // drop the comma after the last digest
+    if (count) p--;                       // drop the comma after the last digest
     *p++ = ']';
     s.resize((size_t)(p - &s[0]));
     return s;
+}
+inline std::string json_hash_path(const std::vector<HashOutput>& path)
+{
+    return json_hash_path_bytes(path.empty() ? nullptr : path[0].data(), path.size());   // arrays of 32 bytes lie back to back
 }
 inline std::vector<HashOutput> json_hash_path_parse(const std::string& str)
 {
@@ -377,7 +396,7 @@ struct ProofStream {
     std::vector<std::string> objects;
     size_t read_idx = 0;
 
-    void push(const std::string& obj) { objects.push_back(obj); }                      // :23-25
+    void push(std::string obj) { objects.push_back(std::move(obj)); }                  // :23-25
     std::string pull()                                                                 // :28-33
     {
         if (!(read_idx < objects.size())) throw Panic("ProofStream: cannot pull object; queue empty.");
@@ -1024,15 +1043,13 @@ struct Fri {
                 const FieldElement* er = e.data() + i * 3 * t;
                 for (size_t s = 0; s < t; s++)                                                   // :166-179
                     ps.push(wire::json_string_triple(er[s].to_string(), er[t + s].to_string(), er[2 * t + s].to_string()));
-                auto path_at = [&](size_t base, size_t d, size_t s) {
-                    std::vector<HashOutput> p(d);
-                    for (size_t k = 0; k < d; k++) std::memcpy(p[k].data(), raw.data() + 32 * (at + base + s * d + k), 32);
-                    return p;
+                auto path_at = [&](size_t base, size_t d, size_t s) {                           // the digests as they came back
+                    return wire::json_hash_path_bytes(raw.data() + 32 * (at + base + s * d), d);
                 };
                 for (size_t s = 0; s < t; s++) {                                                 // :182-204
-                    ps.push(wire::json_hash_path(path_at(0, depth[i], s)));
-                    ps.push(wire::json_hash_path(path_at(t * depth[i], depth[i], s)));
-                    ps.push(wire::json_hash_path(path_at(2 * t * depth[i], depth[i + 1], s)));
+                    ps.push(path_at(0, depth[i], s));
+                    ps.push(path_at(t * depth[i], depth[i], s));
+                    ps.push(path_at(2 * t * depth[i], depth[i + 1], s));
                 }
                 at += t * (2 * depth[i] + depth[i + 1]);
             }
