@@ -2030,14 +2030,14 @@ extern "C" int32_t stark_fri_query_all(stark_fri_layers* l, const uint64_t* top_
     const size_t tab_words = rounds * (sizeof(QueryRound) / sizeof(uint64_t));
     const size_t val_bytes = rounds * 3 * count * sizeof(fe);
     std::vector<uint64_t> in((tab_words + rounds * 3 * count + 3) / 4 * 4);       // whole 32-byte units: values and paths follow
-    QueryRound* tab = (QueryRound*)in.data();
     size_t path_digests = 0;
     for (size_t r = 0; r < rounds; r++) {
         const size_t n = l->len[r], n_next = l->len[r + 1], half = n / 2;
         if (n_next < half) return fail(STARK_ELENGTH, "a layer is shorter than half of the one before");
         const int depth = log2_exact(n), depth_next = log2_exact(n_next);
-        tab[r] = QueryRound{l->cw[r], l->cw[r + 1], l->tree[r], l->tree[r + 1], n, n_next, path_digests,
-                            (uint32_t)depth, (uint32_t)depth_next};
+        const QueryRound q{l->cw[r], l->cw[r + 1], l->tree[r], l->tree[r + 1], n, n_next, path_digests,
+                           (uint32_t)depth, (uint32_t)depth_next};
+        memcpy(in.data() + r * (sizeof(QueryRound) / sizeof(uint64_t)), &q, sizeof(q));
         path_digests += count * (2 * (size_t)depth + (size_t)depth_next);
         uint64_t* ir = in.data() + tab_words + r * 3 * count;
         for (size_t i = 0; i < count; i++) {
