@@ -328,6 +328,32 @@ def test_fri_fold_vs_oracle(ctx, log_n):
         assert np.array_equal(ctx.fri_fold(cw, alpha, G, w3), oc.fri_fold(cw, alpha, G, w3))
 
 
+@pytest.mark.parametrize("log_n", [3, 9, 12])
+def test_fri_fold_structured_inputs_and_challenges(ctx, log_n):
+    """Folds whose results sit at the ends of the field (0, 1, p - 1) or whose difference a - b vanishes, with
+    challenges 0, 1, p - 1 and the one that makes a weight zero: the exact-reduction path behind the lazy sum."""
+    n = 1 << log_n
+    half = n // 2
+    omega = so.primitive_nth_root(n)
+    rnd = oc.splitmix(n, 4242 + log_n)
+    top = oc.fe(so.P - 1)
+    same = rnd.copy()
+    same[half:] = same[:half]                                  # a = b everywhere
+    ends = np.zeros_like(rnd)
+    ends[::2] = top                                            # 0 and p - 1 alternating
+    upper = np.zeros_like(rnd)
+    upper[half:] = top                                         # a = 0, b = p - 1
+    ones = np.zeros_like(rnd)
+    ones[:, 0] = 1
+    all_top = np.zeros_like(rnd)
+    all_top[:] = top
+    # alpha = offset makes the weight of b vanish at i = 0 (1 - alpha / x_0 = 0) and doubles nothing else
+    for alpha in (0, 1, so.P - 1, G, (so.P + 1) // 2):
+        for cw in (np.zeros_like(rnd), all_top, ones, same, ends, upper, rnd):
+            got = ctx.fri_fold(np.ascontiguousarray(cw), alpha, G, omega)
+            assert np.array_equal(got, oc.fri_fold(np.ascontiguousarray(cw), alpha, G, omega)), (alpha, log_n)
+
+
 def test_fri_fold_literal_reference_form(ctx):
     n = 64
     cw = oc.splitmix(n, 2)
