@@ -302,8 +302,8 @@ def launch_ranks(n_ranks: int, argv) -> int:
                 procs[r].kill()
         time.sleep(0.05)
     reader.join(timeout=10)
-    for l in lines:
-        sys.stdout.write(l)
+    for l in lines:                                              # the line, not what a transport library printed beside it
+        (sys.stdout if l.lstrip().startswith("{") else sys.stderr).write(l)
     sys.stdout.flush()
     return worst
 
