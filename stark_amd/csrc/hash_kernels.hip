@@ -3,6 +3,7 @@
 // node = BLAKE2b-256(left || right), level-order pairing) and
 // src/modules/fri.rs:133-138 (split and fold).
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 #include "internal.hpp"
 
@@ -386,29 +387,37 @@ __device__ __forceinline__ u64 quad_blake2b(const QuadState& st, uint32_t q, con
     return st.a0 ^ a ^ quad_rotate<QUAD_ROT2>(c);            // c_i sits in lane i + 2 after the last diagonal step
 }
 
-// Tail of a tree: every workgroup reduces TAIL_CHILDREN consecutive digests of
+// Tail of a tree: every workgroup reduces c_blk <= TAIL_CHILDREN consecutive digests of
 // one level (or the whole level if it is smaller) to a single node, writing
 // every level it passes to the tree.  Levels alternate between two LDS buffers
-// of 128-byte message slots whose upper halves stay zero.
+// of 128-byte message slots whose upper halves stay zero; the buffers are sized
+// by the launch for the children a workgroup takes (c_blk / 2 slots and c_blk / 4),
+// and a workgroup has 2 c_blk threads (four lanes per node of its first level), at least a wave.
 constexpr uint32_t TAIL_CHILDREN = 512;
-constexpr uint32_t TAIL_THREADS = 1024;
 
 struct TailBuffers {
-    uint8_t a[(TAIL_CHILDREN / 2) * 128];
-    uint8_t b[(TAIL_CHILDREN / 4) * 128];
+    uint8_t* a;
+    uint8_t* b;
 };
+static inline uint32_t tail_threads(size_t c_blk) { return c_blk < 32 ? 64u : (uint32_t)(2 * c_blk); }
+static inline size_t tail_lds_bytes(size_t c_blk) { return (c_blk / 2 + c_blk / 4 + 2) * 128; }
 
-__device__ __forceinline__ void tail_zero_padding(TailBuffers& lds, uint32_t t)
+__device__ __forceinline__ TailBuffers tail_buffers(uint8_t* lds, uint32_t c_blk)
+{
+    return TailBuffers{lds, lds + ((c_blk >> 1) + 1) * 128};
+}
+
+__device__ __forceinline__ void tail_zero_padding(const TailBuffers& lds, uint32_t t, uint32_t c_blk)
 {
     const uint4 z = make_uint4(0, 0, 0, 0);
-    *(uint4*)(lds.a + (t >> 2) * 128 + 64 + (t & 3) * 16) = z;
-    if (t < TAIL_THREADS / 2) *(uint4*)(lds.b + (t >> 2) * 128 + 64 + (t & 3) * 16) = z;
+    if (t < 2 * c_blk) *(uint4*)(lds.a + (t >> 2) * 128 + 64 + (t & 3) * 16) = z;
+    if (t < c_blk) *(uint4*)(lds.b + (t >> 2) * 128 + 64 + (t & 3) * 16) = z;
 }
 
 // lds.a holds this workgroup's c_blk children (child k in slot k/2, half k%2).
 // When the launch is a single workgroup its last node is the root, which is
 // also stored to root_out if that is not null (host-mapped memory).
-__device__ __forceinline__ void tail_reduce(TailBuffers& lds, digest* level, uint32_t m, uint32_t c_blk,
+__device__ __forceinline__ void tail_reduce(const TailBuffers& lds, digest* level, uint32_t m, uint32_t c_blk,
                                             digest* root_out)
 {
     const uint32_t t = threadIdx.x, q = t & 3, h = t >> 2;
@@ -432,12 +441,13 @@ __device__ __forceinline__ void tail_reduce(TailBuffers& lds, digest* level, uin
     }
 }
 
-__global__ __launch_bounds__(TAIL_THREADS) void merkle_tail_kernel(digest* level, uint32_t m, uint32_t c_blk,
-                                                                   digest* root_out)
+__global__ __launch_bounds__(2 * TAIL_CHILDREN) void merkle_tail_kernel(digest* level, uint32_t m, uint32_t c_blk,
+                                                                        digest* root_out)
 {
-    __shared__ __align__(16) TailBuffers lds;
+    extern __shared__ __align__(16) uint8_t tail_lds[];
+    const TailBuffers lds = tail_buffers(tail_lds, c_blk);
     const uint32_t t = threadIdx.x;                                     // c_blk = children per workgroup
-    tail_zero_padding(lds, t);
+    tail_zero_padding(lds, t, c_blk);
     // thread t carries bytes 16t..16t+15 of this workgroup's children into slot t/4
     if (t < 2 * c_blk) {
         const uint4* src = (const uint4*)(level + (size_t)blockIdx.x * c_blk);
@@ -484,8 +494,8 @@ hipError_t launch_merkle_reduce(digest* level, size_t m, hipStream_t s, digest* 
     }
     while (m_tree > 1) {
         const size_t c_blk = m_tree < TAIL_CHILDREN ? m_tree : TAIL_CHILDREN;
-        hipLaunchKernelGGL(merkle_tail_kernel, dim3((uint32_t)(m / c_blk)), dim3(TAIL_THREADS), 0, s, level,
-                           (uint32_t)m, (uint32_t)c_blk, n_trees == 1 ? root_out : nullptr);
+        hipLaunchKernelGGL(merkle_tail_kernel, dim3((uint32_t)(m / c_blk)), dim3(tail_threads(c_blk)), tail_lds_bytes(c_blk),
+                           s, level, (uint32_t)m, (uint32_t)c_blk, n_trees == 1 ? root_out : nullptr);
         tail_advance(level, m, c_blk);
         m_tree /= c_blk;
     }
@@ -580,15 +590,15 @@ __global__ __launch_bounds__(256) void fri_fold_subtree_kernel(FoldArgs a)
     level2[first / 4 + lane] = node_digest(l, r);
 }
 
-// Small layers: fold, leaf digests and the first nine tree levels in one launch
-// (a.leaf_out is level 0 of the new layer's tree, a.half its leaf count).
-__global__ __launch_bounds__(TAIL_THREADS) void fri_fold_tail_kernel(FoldArgs a, digest* root_out)
+// Small layers: fold, leaf digests and the first tree levels in one launch
+// (a.leaf_out is level 0 of the new layer's tree, a.half its leaf count, c_blk the leaves a workgroup takes).
+__global__ __launch_bounds__(2 * TAIL_CHILDREN) void fri_fold_tail_kernel(FoldArgs a, uint32_t c_blk, digest* root_out)
 {
-    __shared__ __align__(16) TailBuffers lds;
+    extern __shared__ __align__(16) uint8_t tail_lds[];
+    const TailBuffers lds = tail_buffers(tail_lds, c_blk);
     const uint32_t t = threadIdx.x;
     const uint32_t m = (uint32_t)a.half;
-    const uint32_t c_blk = m < TAIL_CHILDREN ? m : TAIL_CHILDREN;
-    tail_zero_padding(lds, t);
+    tail_zero_padding(lds, t, c_blk);
     if (t < c_blk) {
         const size_t i = (size_t)blockIdx.x * c_blk + t;
         fe o = fold_one(a, i);
@@ -599,6 +609,22 @@ __global__ __launch_bounds__(TAIL_THREADS) void fri_fold_tail_kernel(FoldArgs a,
         if (root_out && m == 1) *root_out = d;
     }
     tail_reduce(lds, a.leaf_out, m, c_blk, root_out);
+}
+
+// Leaves per workgroup of the fold-and-tree launch of a small layer.  A workgroup's first levels are bound by
+// the one CU it runs on (four lanes per node: 256 nodes are sixteen waves, 4.9 us; 128 nodes 2.4 us; from 64
+// nodes down a level costs the 1.4 us of one compression), so a layer is cut into more, smaller workgroups
+// than the tree tail's 512 children while it has more than one of them, and the levels that moves to the
+// following tail launch run there at the floor.
+static size_t fold_tail_leaves(size_t half)
+{
+    static const size_t leaves = [] {
+        const char* e = getenv("STARK_FRI_TAIL_LEAVES");
+        size_t v = e ? (size_t)atol(e) : 256;
+        if (v < 8 || v > TAIL_CHILDREN || (v & (v - 1))) v = 256;
+        return v;
+    }();
+    return half <= 2 * leaves ? (half < TAIL_CHILDREN ? half : (size_t)TAIL_CHILDREN) : leaves;
 }
 
 // Fold layer r into layer r+1 and build layer r+1's whole tree.
@@ -612,8 +638,9 @@ hipError_t launch_fri_fold_commit(const FoldArgs& a, hipStream_t s, digest* root
         if (e != hipSuccess) return e;
         return launch_merkle_reduce(a.leaf_out + a.half + a.half / 2, a.half / 4, s, root_out);
     }
-    const size_t c_blk = a.half < TAIL_CHILDREN ? a.half : TAIL_CHILDREN;
-    hipLaunchKernelGGL(fri_fold_tail_kernel, dim3((uint32_t)(a.half / c_blk)), dim3(TAIL_THREADS), 0, s, a, root_out);
+    const size_t c_blk = fold_tail_leaves(a.half);
+    hipLaunchKernelGGL(fri_fold_tail_kernel, dim3((uint32_t)(a.half / c_blk)), dim3(tail_threads(c_blk)), tail_lds_bytes(c_blk), s,
+                       a, (uint32_t)c_blk, root_out);
     digest* level = a.leaf_out;
     size_t m = a.half;
     tail_advance(level, m, c_blk);
