@@ -2,7 +2,7 @@
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-idx = [i for i, r in enumerate(rows) if 'leaf_hash_kernel' in r['Kernel_Name']]
+idx = [i for i, r in enumerate(rows) if ('leaf_hash_kernel' in r['Kernel_Name'] or 'leaf_subtree_kernel' in r['Kernel_Name'])]
 s = idx[-1]
 t0 = int(rows[s]['Start_Timestamp'])
 prev_end = t0
